@@ -1,0 +1,471 @@
+"""CPU oracle for the DFPN / CHN hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch, *functional* restatement (plain ``torch`` fp32 ops
+on CPU tensors, parameters passed as a flat ``state_dict``) of the reference's
+training-step path.  It exists to CHECK the HIP product path and to be timed as
+the ``cpu_baseline`` leg of ``bench.py``.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import it;
+nothing under ``master_thesis_amd/`` does.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the reference
+itself (``/root/reference``, this container only) and stores its outputs for
+seeded inputs/weights under ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
+checks every function below against those fixtures.
+
+Every function cites the reference ``file:line`` (relative to
+``/root/reference/master_thesis/``) whose behaviour it restates.
+
+One intentional deviation: ``chn_compute_loss`` folds the
+reference-frame axis into the batch for the Sobel term, because the reference
+(`model_chn.py:371-373`) feeds a 5-D tensor to ``conv2d`` and raises for R>1.
+For R==1 the two are identical (checked against the golden).
+"""
+import torch
+import torch.nn.functional as F
+
+MEAN = (0.485, 0.456, 0.406)
+STD = (0.229, 0.224, 0.225)
+VGG16_CFG_D = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M',
+               512, 512, 512, 'M', 512, 512, 512, 'M')
+
+
+def _mean_std(ref, ndim):
+    shape = [1, 3] + [1] * (ndim - 2)
+    return (torch.tensor(MEAN, dtype=ref.dtype).view(shape),
+            torch.tensor(STD, dtype=ref.dtype).view(shape))
+
+
+def get_indexes(size):
+    """model_dfpn.py:458-473 / model_chn.py:442-457."""
+    t = size // 2
+    return t, [i for i in range(size) if i != t]
+
+
+# --------------------------------------------------------------------------
+# utils.py
+# --------------------------------------------------------------------------
+def fold_frames(x):
+    """(B,C,F,H,W) -> (B*F,C,H,W) with b-major, f-minor ordering
+    (the ``transpose(1, 2).reshape`` idiom, e.g. utils.py:94)."""
+    b, c, f, h, w = x.shape
+    return x.transpose(1, 2).reshape(b * f, c, h, w)
+
+
+def unfold_frames(x, b):
+    """(B*F,C,H,W) -> (B,C,F,H,W)."""
+    bf, c, h, w = x.shape
+    return x.reshape(b, bf // b, c, h, w).transpose(1, 2)
+
+
+def align_set(x, v, flow):
+    """FlowsUtils.align_set, utils.py:77-104: bilinear(zeros, align_corners)
+    warp of the frames, nearest warp of the visibility maps."""
+    b = x.shape[0]
+    h, w = x.shape[-2:]
+    grid = flow.reshape(-1, h, w, 2)
+    xa = F.grid_sample(fold_frames(x), grid, mode='bilinear',
+                       padding_mode='zeros', align_corners=True)
+    va = F.grid_sample(fold_frames(v), grid, mode='nearest',
+                       padding_mode='zeros', align_corners=True)
+    return unfold_frames(xa, b), unfold_frames(va, b)
+
+
+def resize_flow(flow, size, mode='nearest'):
+    """FlowsUtils.resize_flow, utils.py:106-126."""
+    b, f, h, w, _ = flow.shape
+    chan_first = flow.reshape(b * f, h, w, 2).permute(0, 3, 1, 2)
+    if mode == 'bilinear':
+        r = F.interpolate(chan_first, size, mode='bilinear',
+                          align_corners=False)
+    else:
+        r = F.interpolate(chan_first, size, mode='nearest')
+    return r.permute(0, 2, 3, 1).reshape(b, f, size[0], size[1], 2)
+
+
+def resize_set(x, v, y, size):
+    """TransformsUtils.resize_set, utils.py:511-549."""
+    b = x.shape[0]
+    s = (size, size)
+    xn = F.interpolate(fold_frames(x), s, mode='bilinear', align_corners=False)
+    vn = F.interpolate(fold_frames(v), s, mode='nearest')
+    yn = F.interpolate(fold_frames(y), s, mode='bilinear', align_corners=False)
+    return unfold_frames(xn, b), unfold_frames(vn, b), unfold_frames(yn, b)
+
+
+def resize_set_bis(x_t, m_t, x_r, m_r, size):
+    """TransformsUtils.resize_set_bis, utils.py:551-595 (identity when the
+    size already matches)."""
+    b, c, r, h, w = x_r.shape
+    if (h, w) == tuple(size):
+        return x_t, m_t, x_r, m_r
+    xt = F.interpolate(x_t, size, mode='bilinear', align_corners=False)
+    mt_ = F.interpolate(m_t, size, mode='nearest')
+    xr = unfold_frames(F.interpolate(fold_frames(x_r), size, mode='bilinear',
+                                     align_corners=False), b)
+    mr = unfold_frames(F.interpolate(fold_frames(m_r), size, mode='nearest'), b)
+    return xt, mt_, xr, mr
+
+
+def masked_l1(y_hat, y, mask, batch_mask=None, reduction='mean', weight=1):
+    """LossesUtils.masked_l1, utils.py:138-169.  All-false batch mask gives a
+    shape-[1] zero; otherwise samples are selected before the reduction."""
+    if batch_mask is not None:
+        sel = torch.as_tensor(batch_mask, dtype=torch.bool)
+        if not bool(sel.any()):
+            return torch.zeros(1)
+        y_hat, y, mask = y_hat[sel], y[sel], mask[sel]
+    diff = (y_hat * mask - y * mask).abs()
+    if reduction == 'sum':
+        return weight * diff.sum() / (mask.sum() + 1e-9)
+    return weight * diff.mean()
+
+
+def sobel_grads(x):
+    """Depth-wise Sobel H and V responses, utils.py:131-136, 211-214."""
+    gh = torch.tensor([[1., 0., -1.], [2., 0., -2.], [1., 0., -1.]])
+    gv = torch.tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]])
+    c = x.shape[1]
+    wh = gh.view(1, 1, 3, 3).repeat(c, 1, 1, 1)
+    wv = gv.view(1, 1, 3, 3).repeat(c, 1, 1, 1)
+    return torch.cat((F.conv2d(x, wh, padding=1, groups=c),
+                      F.conv2d(x, wv, padding=1, groups=c)), dim=1)
+
+
+def grad_loss(y_hat, y, weight=1):
+    """LossesUtils.grad with reduction='mean', utils.py:193-224."""
+    return weight * (sobel_grads(y_hat) - sobel_grads(y)).abs().mean()
+
+
+def perceptual(sd, prefix, y_hat, y, weight=1):
+    """LossesUtils.perceptual, utils.py:171-191 (VGG taps are detached)."""
+    a = vgg_features(sd, prefix, y_hat.contiguous())
+    b = vgg_features(sd, prefix, y.contiguous())
+    total = 0
+    for fa, fb in zip(a, b):
+        total = total + (fa - fb).abs().mean()
+    return total * weight / len(a)
+
+
+# --------------------------------------------------------------------------
+# model_vgg.py
+# --------------------------------------------------------------------------
+def vgg_features(sd, prefix, x, normalize_input=True):
+    """VGGFeatures.forward, model_vgg.py:26-44: VGG-16 'D' features, the five
+    post-max-pool taps, each detached."""
+    if normalize_input:
+        mean, std = _mean_std(x, 4)
+        x = (x - mean) / std
+    taps, idx = [], 0
+    for v in VGG16_CFG_D:
+        if v == 'M':
+            x = F.max_pool2d(x, 2, 2)
+            taps.append(x.detach())
+            idx += 1
+        else:
+            x = F.relu(F.conv2d(x, sd[f'{prefix}features.{idx}.weight'],
+                                sd[f'{prefix}features.{idx}.bias'], padding=1))
+            idx += 2
+    return taps
+
+
+# --------------------------------------------------------------------------
+# model_dfpn.py
+# --------------------------------------------------------------------------
+def correlation_masked_4d(t_feats, v_t, r_feats, v_r):
+    """CorrelationVGG.correlation_masked_4d, model_dfpn.py:534-565.
+    t_feats (B,C,H,W), r_feats (B,C,R,H,W); masks optional.  eps is added to
+    each L2 norm after the sqrt.  Output (B,R,H,W,H,W) = [b,r,h_t,w_t,h_r,w_r]."""
+    b, c, r, h, w = r_feats.shape
+    if v_t is not None:
+        t_feats = t_feats * v_t
+    if v_r is not None:
+        r_feats = r_feats * v_r
+    tgt = t_feats.reshape(b, c, h * w).transpose(1, 2).unsqueeze(1)  # B,1,P,C
+    tgt = tgt / (tgt.norm(dim=3, keepdim=True) + 1e-9)
+    ref = r_feats.reshape(b, c, r, h * w).permute(0, 2, 1, 3)        # B,R,C,P
+    ref = ref / (ref.norm(dim=2, keepdim=True) + 1e-9)
+    return torch.matmul(tgt, ref).reshape(b, r, h, w, h, w)
+
+
+def _conv(sd, key, x, stride=1, padding=1):
+    return F.conv2d(x, sd[key + '.weight'], sd[key + '.bias'], stride=stride,
+                    padding=padding)
+
+
+def separable_conv4d(sd, prefix, corr):
+    """SeparableConv4d.forward, model_dfpn.py:607-626."""
+    b, r, h, w = corr.shape[:4]
+    p = h * w
+    x = corr.reshape(b * r * p, 1, h, w)
+    x = F.relu(_conv(sd, prefix + 'conv_1.0', x))
+    x = F.relu(_conv(sd, prefix + 'conv_1.2', x))
+    x = _conv(sd, prefix + 'conv_1.4', x)
+    ch = x.shape[1]
+    # [b,r,pt,C,pr] -> [b,r,pr,C,pt]
+    x = x.reshape(b, r, p, ch, p).permute(0, 1, 4, 3, 2).reshape(-1, ch, h, w)
+    x = F.relu(_conv(sd, prefix + 'conv_2.0', x))
+    x = F.relu(_conv(sd, prefix + 'conv_2.2', x))
+    x = _conv(sd, prefix + 'conv_2.4', x)
+    # [b,r,h_r,w_r,h_t,w_t] -> [b,r,h_t,w_t,h_r,w_r]
+    return x.reshape(b, r, h, w, h, w).permute(0, 1, 4, 5, 2, 3)
+
+
+MIXER_SPEC = (  # (index in nn.Sequential, kernel, relu-after)
+    (0, 5, True), (2, 3, True), (4, 3, True), (6, 5, True), (8, 3, True),
+    (10, 3, True), (12, 5, True), (14, 3, True), (16, 3, True), (18, 5, True),
+    (20, 3, True), (22, 3, False), (23, 5, False), (24, 3, False))
+
+
+def corr_mixer(sd, prefix, corr):
+    """AlignmentCorrelationMixer.forward, model_dfpn.py:638-674."""
+    b, r, h, w = corr.shape[:4]
+    x = corr.reshape(b * r, -1, 16, 16)
+    for idx, k, relu in MIXER_SPEC:
+        x = _conv(sd, f'{prefix}mixer.{idx}', x, padding=k // 2)
+        if relu:
+            x = F.relu(x)
+    return x.reshape(b, r, 2, h, w).permute(0, 1, 3, 4, 2)
+
+
+FLOW_SPEC = (  # (index, kind, kernel, stride) ; ReLU after all but the last
+    (0, 'c', 5, 1), (2, 'c', 3, 1), (4, 'c', 5, 2), (6, 'c', 5, 1),
+    (8, 'c', 3, 1), (10, 'c', 3, 2), (12, 'c', 5, 1), (14, 'c', 3, 1),
+    (16, 'c', 3, 2), (18, 'c', 5, 1), (20, 'c', 3, 1), (22, 't', 3, 2),
+    (24, 'c', 5, 1), (26, 'c', 3, 1), (28, 't', 3, 2), (30, 'c', 5, 1),
+    (32, 'c', 3, 1), (34, 't', 5, 2), (36, 'c', 5, 1), (38, 'c', 3, 1),
+    (40, 'c', 3, 1))
+
+
+def flow_estimator_pack(x_t, m_t, x_r, m_r, flow_pre):
+    """The 10-channel input of FlowEstimator, model_dfpn.py:732-741."""
+    b, c, r, h, w = x_r.shape
+    rep = lambda a: a.unsqueeze(1).repeat(1, r, 1, 1, 1).reshape(  # noqa: E731
+        b * r, a.shape[1], h, w)
+    return torch.cat([fold_frames(x_r), rep(x_t), fold_frames(m_r), rep(m_t),
+                      flow_pre.reshape(b * r, h, w, 2).permute(0, 3, 1, 2)], 1)
+
+
+def flow_estimator(sd, prefix, x_t, m_t, x_r, m_r, flow_pre):
+    """FlowEstimator.forward, model_dfpn.py:686-743."""
+    b, c, r, h, w = x_r.shape
+    x = flow_estimator_pack(x_t, m_t, x_r, m_r, flow_pre)
+    last = FLOW_SPEC[-1][0]
+    for idx, kind, k, s in FLOW_SPEC:
+        key = f'{prefix}nn.{idx}'
+        if kind == 'c':
+            x = _conv(sd, key, x, stride=s, padding=k // 2)
+        else:
+            x = F.conv_transpose2d(x, sd[key + '.weight'], sd[key + '.bias'],
+                                   stride=s, padding=k // 2, output_padding=1)
+        if idx != last:
+            x = F.relu(x)
+    return x.reshape(b, r, 2, h, w).permute(0, 1, 3, 4, 2)
+
+
+def correlation_vgg(sd, prefix, x_t, m_t, x_r, m_r):
+    """CorrelationVGG.forward (use_softmax=False), model_dfpn.py:491-532."""
+    b, c, r, h, w = x_r.shape
+    with torch.no_grad():
+        ft = vgg_features(sd, prefix + 'model_vgg.', x_t, False)[3]
+        fr = vgg_features(sd, prefix + 'model_vgg.', fold_frames(x_r), False)[3]
+    fr = unfold_frames(fr, b)
+    fh, fw = fr.shape[-2:]
+    v_t = F.interpolate(1 - m_t, size=(fh, fw), mode='nearest')
+    v_r = unfold_frames(F.interpolate(1 - fold_frames(m_r), size=(fh, fw),
+                                      mode='nearest'), b)
+    corr = correlation_masked_4d(ft, v_t, fr, v_r)
+    return separable_conv4d(sd, prefix + 'conv.', corr)
+
+
+def dfpn_forward(sd, x_t, m_t, x_r, m_r, prefix=''):
+    """DFPN.forward, model_dfpn.py:46-101."""
+    h, w = x_r.shape[-2:]
+    mean4, std4 = _mean_std(x_t, 4)
+    mean5, std5 = _mean_std(x_r, 5)
+    x_t = (x_t - mean4) / std4
+    x_r = (x_r - mean5) / std5
+    sq = resize_set_bis(x_t, m_t, x_r, m_r, (256, 256))
+    s64 = resize_set_bis(x_t, m_t, x_r, m_r, (64, 64))
+    corr = correlation_vgg(sd, prefix + 'corr.', *sq)
+    flow_16 = corr_mixer(sd, prefix + 'corr_mixer.', corr)
+    flow_64 = flow_estimator(sd, prefix + 'flow_64.', *s64,
+                             resize_flow(flow_16, (64, 64), 'bilinear'))
+    flow_256 = flow_estimator(sd, prefix + 'flow_256.', *sq,
+                              resize_flow(flow_64, (256, 256), 'bilinear'))
+    return corr, flow_16, flow_64, resize_flow(flow_256, (h, w), 'bilinear')
+
+
+def dfpn_align(sd, x_t, m_t, x_r, m_r, prefix=''):
+    """DFPN.align, model_dfpn.py:103-133."""
+    with torch.no_grad():
+        flow = dfpn_forward(sd, x_t, m_t, x_r, m_r, prefix)[3]
+    xa, va = align_set(x_r, 1 - m_r, flow)
+    v_map = (va - (1 - m_t).unsqueeze(2)).clamp(0, 1)
+    return xa, va, v_map
+
+
+def dfpn_train_val_wrapper(sd, x, m, y, flow_gt, flows_use, t, r_list,
+                           prefix=''):
+    """DFPN._train_val_wrapper, model_dfpn.py:310-394 (the GT-flow warps at
+    :358-375 are dead code in the reference and are skipped)."""
+    corr, f16, f64, f256 = dfpn_forward(
+        sd, x[:, :, t], m[:, :, t], x[:, :, r_list], m[:, :, r_list], prefix)
+    x16, v16, y16 = resize_set(x, 1 - m, y, 16)
+    x64, v64, y64 = resize_set(x, 1 - m, y, 64)
+    fgt = flow_gt[:, r_list]
+    f16gt = resize_flow(fgt, (16, 16))
+    f64gt = resize_flow(fgt, (64, 64))
+    xa16, _ = align_set(x16[:, :, r_list], v16[:, :, r_list], f16)
+    xa64, _ = align_set(x64[:, :, r_list], v64[:, :, r_list], f64)
+    xa256, _ = align_set(x[:, :, r_list], (1 - m)[:, :, r_list], f256)
+    return (corr, (x16, x64, x), (v16, v64, 1 - m), (y16, y64, y),
+            (xa16, xa64, xa256), (f16, f64, f256), (f16gt, f64gt, fgt),
+            flows_use)
+
+
+def dfpn_compute_loss(sd, corr, xs, vs, ys, xs_aligned, flows, flows_gt,
+                      flows_use, t, r_list, prefix=''):
+    """DFPN.compute_loss, model_dfpn.py:210-293."""
+    b, c, f, h, w = ys[2].shape
+    with torch.no_grad():
+        y_in = fold_frames(ys[2])
+        if (h, w) != (256, 256):
+            y_in = F.interpolate(y_in, (256, 256), mode='bilinear',
+                                 align_corners=False)
+        feats = vgg_features(sd, prefix + 'model_vgg.', y_in)[3]
+    feats = feats.reshape(b, f, -1, 16, 16).transpose(1, 2)
+    corr_y = correlation_masked_4d(feats[:, :, t], None,
+                                   feats[:, :, r_list], None)
+    corr_loss = (corr - corr_y).abs().mean()
+    fl = [masked_l1(flows[i], flows_gt[i], torch.ones_like(flows[i]),
+                    flows_use) for i in range(3)]
+    r = len(r_list)
+    rec = []
+    for i in (1, 2):
+        out = (((flows[i] < -1).float() + (flows[i] > 1).float())
+               .sum(4).clamp(0, 1).unsqueeze(1))
+        x_t = xs[i][:, :, t].unsqueeze(2).repeat(1, 1, r, 1, 1)
+        v_t = vs[i][:, :, t].unsqueeze(2).repeat(1, 1, r, 1, 1)
+        rec.append(masked_l1(x_t, xs_aligned[i], v_t * (1 - out),
+                             reduction='sum'))
+    items = [corr_loss, fl[0], fl[1], fl[2], rec[0], rec[1]]
+    total = corr_loss + fl[0] + fl[1] + fl[2]
+    total = total + rec[0] + rec[1]
+    return total, items
+
+
+def dfpn_training_step(sd, batch, prefix=''):
+    """DFPN.training_step, model_dfpn.py:135-158."""
+    (x, m), y, info = batch
+    flows_use, flow_gt = info[2], info[4]
+    t, r_list = get_indexes(x.shape[2])
+    out = dfpn_train_val_wrapper(sd, x, m, y, flow_gt, flows_use, t, r_list,
+                                 prefix)
+    return dfpn_compute_loss(sd, *out, t, r_list, prefix=prefix)
+
+
+# --------------------------------------------------------------------------
+# model_chn.py
+# --------------------------------------------------------------------------
+def _lrelu(x):
+    return F.leaky_relu(x, 0.2)
+
+
+def residual_dense_block(sd, prefix, x):
+    """ResidualDenseBlock5C.forward, model_chn.py:602-623."""
+    feats = [x]
+    for i in range(1, 5):
+        feats.append(_lrelu(_conv(sd, f'{prefix}conv{i}', torch.cat(feats, 1))))
+    x5 = _conv(sd, prefix + 'conv5', torch.cat(feats, 1))
+    return 0.2 * x5 + x
+
+
+def rrdb(sd, prefix, x):
+    """RRDB.forward, model_chn.py:573-585."""
+    y = x
+    for j in (1, 2, 3):
+        y = residual_dense_block(sd, f'{prefix}rdb{j}.', y)
+    return 0.2 * y + x
+
+
+def rrdbnet(sd, prefix, x, nb=20):
+    """RRDBNet.forward, model_chn.py:538-555 (conv_first has no activations)."""
+    y = x
+    for i, s in enumerate((1, 1, 2, 1, 2)):
+        y = _conv(sd, f'{prefix}conv_first.{i}', y, stride=s)
+    z = y
+    for k in range(nb):
+        z = rrdb(sd, f'{prefix}rrdb_trunk.{k}.', z)
+    y = y + _conv(sd, prefix + 'trunk_conv', z)
+    y = _lrelu(_conv(sd, prefix + 'upconv1',
+                     F.interpolate(y, scale_factor=2, mode='nearest')))
+    y = _lrelu(_conv(sd, prefix + 'upconv2',
+                     F.interpolate(y, scale_factor=2, mode='nearest')))
+    return _conv(sd, prefix + 'conv_last', _lrelu(_conv(sd, prefix + 'hr_conv', y)))
+
+
+def chn_pack(x_t, v_t, x_ra, v_ra, v_maps):
+    """The 9-channel input of the CHN network, model_chn.py:68-80."""
+    f = x_ra.shape[2]
+    mean, std = _mean_std(x_ra, 5)
+    x_t5 = x_t.unsqueeze(2).repeat(1, 1, f, 1, 1)
+    v_t5 = v_t.unsqueeze(2).repeat(1, 1, f, 1, 1)
+    cat = torch.cat([(x_t5 - mean) / std, (x_ra - mean) / std, v_t5, v_ra,
+                     v_maps], dim=1)
+    return fold_frames(cat), x_t5, v_t5
+
+
+def chn_forward(sd, x_t, v_t, x_ra, v_ra, v_maps, prefix='', nb=20):
+    """CHN.forward, model_chn.py:44-85."""
+    b = x_ra.shape[0]
+    mean, std = _mean_std(x_ra, 5)
+    nn_in, x_t5, v_t5 = chn_pack(x_t, v_t, x_ra, v_ra, v_maps)
+    out = unfold_frames(rrdbnet(sd, prefix + 'nn.', nn_in, nb), b)
+    y_hat = torch.clamp(out * std + mean, 0, 1)
+    return y_hat, v_t5 * x_t5 + (1 - v_t5) * y_hat
+
+
+def chn_compute_loss(sd, y_t, v_t, y_hat, y_hat_comp, v_map, prefix=''):
+    """CHN.compute_loss, model_chn.py:324-376 (Sobel term on F-folded tensors,
+    see the module docstring)."""
+    f = y_hat.shape[2]
+    target = y_t.unsqueeze(2).repeat(1, 1, f, 1, 1)
+    nh = v_t.unsqueeze(2).repeat(1, 1, f, 1, 1)
+    l_nh = masked_l1(y_hat, target, nh, reduction='sum', weight=0.50)
+    l_vh = masked_l1(y_hat, target, v_map, reduction='sum', weight=2)
+    l_nvh = masked_l1(y_hat_comp, target, (1 - nh) - v_map, reduction='sum',
+                      weight=1)
+    l_p = perceptual(sd, prefix + 'model_vgg.', fold_frames(y_hat),
+                     fold_frames(target), weight=0.50)
+    l_g = grad_loss(fold_frames(y_hat), fold_frames(target), weight=1)
+    items = [l_nh, l_vh, l_nvh, l_p, l_g]
+    return l_nh + l_vh + l_nvh + l_p + l_g, items
+
+
+def chn_training_step(sd, batch, prefix='', aligner_prefix='model_aligner.',
+                      nb=20):
+    """CHN.training_step with a DFPN aligner, model_chn.py:256-280."""
+    (x, m), y, info = batch
+    t, r_list = get_indexes(x.shape[2])
+    xa, va, v_map = dfpn_align(sd, x[:, :, t], m[:, :, t], x[:, :, r_list],
+                               m[:, :, r_list], prefix + aligner_prefix)
+    y_hat, y_hat_comp = chn_forward(sd, x[:, :, t], 1 - m[:, :, t], xa, va,
+                                    v_map, prefix, nb)
+    return chn_compute_loss(sd, y[:, :, t], (1 - m)[:, :, t], y_hat,
+                            y_hat_comp, v_map, prefix)
+
+
+# --------------------------------------------------------------------------
+# model_cpn.py (warp tail only)
+# --------------------------------------------------------------------------
+def cpn_warp(x_r, m_r, m_t, theta):
+    """The affine warp at the end of CPN.align, model_cpn.py:75-91:
+    affine_grid / bilinear grid_sample with align_corners=False; visibility is
+    the bilinear warp thresholded at 0.5."""
+    b, c, r, h, w = x_r.shape
+    grid = F.affine_grid(theta, [theta.shape[0], c, h, w], align_corners=False)
+    xa = unfold_frames(F.grid_sample(fold_frames(x_r), grid,
+                                     align_corners=False), b)
+    va = unfold_frames((F.grid_sample(1 - fold_frames(m_r), grid,
+                                      align_corners=False) > 0.5).float(), b)
+    return xa, va, (va - (1 - m_t.unsqueeze(2))).clamp(0, 1)
