@@ -1,0 +1,254 @@
+/* mt355 -- C ABI of the MI355X (gfx950) kernels behind the DFPN / CHN hot path.
+ *
+ * The reference (davidalvarezdlt/master_thesis) has NO FFI: every op on its hot
+ * path is a torch.nn.functional call inside model_dfpn.py / model_chn.py /
+ * utils.py / model_vgg.py.  Each entry point below replaces one such call-site
+ * group (cited as reference file:line, relative to master_thesis/) and is what
+ * a binding for this path would bind (see INTEGRATION.md for the ctypes stub).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all device pointers are HBM
+ *     addresses on the current HIP device; `stream` is a hipStream_t (as void*).
+ *   - return 0 on success, a negative mt_status otherwise; no exceptions cross
+ *     the ABI; mt_last_error() gives a thread-local message.
+ *   - nothing allocates or synchronises: the caller passes workspaces.
+ *   - activations inside the engine are "NHWC4": float32, channels innermost
+ *     and contiguous, the channel count padded to a multiple of 4 with ZEROS;
+ *     image / row / pixel strides are explicit (in floats) so that channel
+ *     windows of a wider buffer (dense blocks) and transposed pixel orders
+ *     (SeparableConv4d's permute) are addressed in place.
+ */
+#ifndef MT355_H
+#define MT355_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum mt_status {
+  MT_OK = 0,
+  MT_ERR_ARG = -1,      /* bad shape / alignment / null pointer */
+  MT_ERR_LAUNCH = -2,   /* hipLaunchKernel failed (message in mt_last_error) */
+  MT_ERR_WORKSPACE = -3 /* workspace too small */
+};
+
+enum mt_act { MT_ACT_NONE = 0, MT_ACT_RELU = 1, MT_ACT_LRELU02 = 2 };
+
+int mt_version(void);
+const char* mt_last_error(void);
+
+/* A strided NHWC4 view: element (n, y, x, c) lives at
+ * p[(n / n_in)*sg + (n % n_in)*sn + y*sh + x*sw + c], c < C (C % 4 == 0,
+ * p 16-byte aligned, strides % 4 == 0).  The two-level image index (groups of
+ * n_in images, group stride sg) expresses SeparableConv4d's
+ * (target position <-> reference position) permute, model_dfpn.py:621-623,
+ * as pure addressing; plain tensors use n_in = N, sg = 0.  mt_conv honours it
+ * on x and y, mt_wgrad on d and g; every other entry point needs n_in >= N. */
+typedef struct {
+  float* p;
+  int64_t sn, sh, sw;
+  int32_t N, H, W, C;
+  int32_t n_in;
+  int64_t sg;
+} mt_view;
+
+/* One convolution-shaped contraction  (replaces every F.conv2d /
+ * F.conv_transpose2d call-site and its autograd backward-data:
+ * model_dfpn.py:596-605,638-660,686-711; model_chn.py:522-535,602-606;
+ * model_vgg.py:40-41):
+ *
+ *   acc[n,y,x,o] = sum_{kh,kw,c} X[n, iy, ix, c] * Wt[o][kh][kw][c]
+ *   gather (transposed == 0):  iy = y*stride - pad + kh            (conv fwd,
+ *                                                     conv_transpose bwd-data)
+ *   gather (transposed == 1):  iy = (y + pad - kh) / stride, taken only when
+ *                              divisible                (conv bwd-data,
+ *                                                        conv_transpose fwd)
+ *   `ups` : the gathered tensor is a nearest x2^ups up-sampling of X
+ *           (model_chn.py:550,553): logical size (H<<ups, W<<ups), physical
+ *           index = logical >> ups.
+ *   epilogue:  v = act(acc + bias[o]) * alpha
+ *              v += beta * R[n,y,x,o]                    (R optional)
+ *              v += Y[n,y,x,o]                           (when accumulate)
+ *              v *= act'(D[n,y,x,o])  for o >= dact_c0   (D optional: the
+ *                     saved activation whose derivative gates this gradient)
+ *              Y[n,y,x,o] = v
+ * Wt is [Y.C][KH*KW*X.C] (see mt_weight_pack); bias is [Y.C] or NULL.
+ */
+typedef struct {
+  mt_view x;          /* gathered input  */
+  mt_view y;          /* output          */
+  const float* wt;
+  const float* bias;
+  int32_t KH, KW, stride, pad, transposed, ups;
+  int32_t act;
+  float alpha;
+  mt_view res;        /* res.p == NULL: none */
+  float beta;
+  mt_view dsrc;       /* dsrc.p == NULL: none */
+  int32_t dact, dact_c0;
+  int32_t accumulate;
+} mt_conv;
+
+int mt_conv_run(const mt_conv* d, void* stream);
+/* slow one-thread-per-output restatement of mt_conv_run (self-check only) */
+int mt_conv_run_naive(const mt_conv* d, void* stream);
+
+/* Weight gradient (autograd of the same call-sites):
+ *   dW[a][kh][kw][b] = sum_{n,y,x} D[n,y,x,a] * G[n, y*stride-pad+kh, x*..., b]
+ * D is iterated densely, G is gathered (conv: D = dY, G = X;
+ * conv_transpose: D = X, G = dY).  Partial sums of `splits` pixel ranges go to
+ * `slabs` ([splits][D.C][KH*KW][G.C] floats) and are reduced by
+ * mt_wgrad_reduce, which also un-packs into the parameter's own layout.
+ */
+typedef struct {
+  mt_view d;
+  mt_view g;
+  int32_t KH, KW, stride, pad, ups;
+  int32_t splits;
+  float* slabs;
+} mt_wgrad;
+
+int mt_wgrad_run(const mt_wgrad* d, void* stream);
+int64_t mt_wgrad_slab_floats(const mt_wgrad* d);
+/* dst[a*sa + b*sb + t*st] (+)= sum_s slabs[s][a][t][b], a < A, b < B, t < T;
+ * slabs rows are padded to AP x T x BP. */
+int mt_wgrad_reduce(const float* slabs, int32_t splits, int32_t AP, int32_t T,
+                    int32_t BP, float* dst, int32_t A, int32_t B, int64_t sa,
+                    int64_t sb, int64_t st, int32_t accumulate, void* stream);
+/* db[c] (+)= sum_pixels D[n,y,x,c], c < C (ws: >= 256*D.C floats) */
+int mt_bias_grad(const mt_view* d, float* db, int32_t C, float* ws,
+                 int32_t accumulate, void* stream);
+
+/* dst[a][t][b] = src[a*sa + b*sb + t*st] for a < A, b < B, else 0;
+ * dst is [AP][T][BP].  Conv2d weight (O,I,kh,kw) -> fwd: a=O, b=I;
+ * bwd-data: a=I, b=O.  ConvTranspose2d weight (I,O,kh,kw) likewise. */
+int mt_weight_pack(const float* src, int32_t A, int32_t B, int32_t T,
+                   int64_t sa, int64_t sb, int64_t st, float* dst, int32_t AP,
+                   int32_t BP, void* stream);
+int mt_pad_vector(const float* src, int32_t n, float* dst, int32_t np, void* stream);
+
+/* ---- layout / streaming kernels --------------------------------------- */
+/* NCHW (arbitrary strides) <-> NHWC4, with optional per-channel affine
+ * (x*scale[c] + shift[c]) (normalisation, model_dfpn.py:71-72,
+ * model_chn.py:73-74,83, model_vgg.py:37-38) */
+int mt_nchw_to_nhwc4(const float* src, int64_t s_n, int64_t s_c, int64_t s_h,
+                     int64_t s_w, int32_t N, int32_t C, int32_t H, int32_t W,
+                     const float* scale, const float* shift, const mt_view* dst,
+                     int32_t c_off, void* stream);
+int mt_nhwc4_to_nchw(const mt_view* src, int32_t c_off, float* dst, int64_t d_n,
+                     int64_t d_c, int64_t d_h, int64_t d_w, int32_t C,
+                     const float* scale, const float* shift, int32_t accumulate,
+                     void* stream);
+/* Build the per-pair network input (FlowEstimator's 10-channel pack,
+ * model_dfpn.py:733-741; CHN's 9-channel pack, model_chn.py:70-80) straight
+ * into an NHWC4 tensor of B*R images: source i contributes channels
+ * [c_off, c_off+C) read from p[b*sb + r*sr + c*sc + y*sy + x*sx], optionally
+ * as v*scale[c] + shift[c] (the mean/std normalisation). sr = 0 repeats a
+ * per-clip tensor over the R references. */
+typedef struct {
+  const float* p;
+  int64_t sb, sr, sc, sy, sx;
+  int32_t C, c_off;
+  const float* scale;
+  const float* shift;
+} mt_pack_src;
+int mt_pack_pairs(const mt_pack_src* srcs, int32_t nsrc, int32_t B, int32_t R,
+                  const mt_view* dst, void* stream);
+/* 2x2/2 max pool (model_vgg.py:40-43) */
+int mt_maxpool2x2(const mt_view* x, const mt_view* y, void* stream);
+/* dX[n,y,x,c] = sum of the 2^ups x 2^ups block of dXup (backward of the
+ * nearest up-sampling folded into mt_conv.ups) */
+int mt_sumpool(const mt_view* dxup, const mt_view* dx, int32_t ups, void* stream);
+/* elementwise on NHWC4 views with equal geometry: y = a*x (+ b*z) */
+int mt_axpby(const mt_view* x, float a, const mt_view* z, float b,
+             const mt_view* y, void* stream);
+/* y = x * act'(s)  (in place allowed) */
+int mt_dact(const mt_view* x, const mt_view* s, int32_t act, const mt_view* y,
+            void* stream);
+
+/* Masked cosine-similarity correlation volume
+ * (CorrelationVGG.correlation_masked_4d, model_dfpn.py:534-565).
+ * ft: NHWC4 (B, h, w, C) target features; fr: NHWC4 (B*R, h, w, C), image
+ * b*R+r is reference r of clip b; P = h*w (P % 4 == 0);
+ * vt: [B][P] visibility or NULL; vr: [B*R][P] or NULL;
+ * out: [B*R][P_t][P_r] floats (== (B,R,h,w,h,w) contiguous);
+ * ws: (B + B*R) * P * C floats of scratch (the normalised features). */
+int mt_corr_masked(const mt_view* ft, const mt_view* fr, const float* vt,
+                   const float* vr, int32_t B, int32_t R, float* out, float* ws,
+                   void* stream);
+/* out[row][c] = x[row][c]*v[row] / (||x[row]*v[row]||_2 + 1e-9), rows = pixels */
+int mt_rownorm(const mt_view* x, const float* v, float* out, void* stream);
+
+/* FlowsUtils.align_set (utils.py:77-104): bilinear+zeros warp of x and nearest
+ * warp of v by an absolute normalised sampling grid.  The 5-D (B,C,F,H,W)
+ * tensors of the reference are addressed in place (the reference first
+ * materialises transpose(1,2).reshape(B*F,C,H,W)); H and W are contiguous.
+ * grid is (B,F,H,W,2) contiguous, last dim (x, y). */
+typedef struct {
+  int32_t B, F, C, H, W;
+  int64_t xb, xc, xf; /* x  (B,C,F,H,W) strides in floats           */
+  int64_t vb, vf;     /* v  (B,1,F,H,W)                              */
+  int64_t ob, oc, of; /* xo (and dxo in the backward)                */
+  int64_t wb, wf;     /* vo                                          */
+} mt_warp_layout;
+/* align_corners=1: DFPN convention (utils.py:96,101); 0: the CPN convention
+ * (model_cpn.py:81-88).  idx (optional, int32 [B*F*H*W][4]) receives per
+ * output pixel (y0, x0) = the top-left bilinear corner and (ny, nx) = the
+ * nearest sample (-1,-1 when outside): the integer indices that must be
+ * bit-exact against the reference. */
+int mt_warp_fwd(const float* x, const float* v, const float* grid,
+                const mt_warp_layout* l, int32_t align_corners, float* xo,
+                float* vo, int32_t* idx, void* stream);
+/* gradient of the bilinear warp wrt the grid: dgrid (B,F,H,W,2) */
+int mt_warp_bwd_grid(const float* x, const float* grid, const float* dxo,
+                     const mt_warp_layout* l, int32_t align_corners,
+                     float* dgrid, void* stream);
+
+/* F.interpolate on planes [NP][H][W] -> [NP][Ho][Wo]
+ * (utils.py:122-124,536-547,583-593; model_dfpn.py:246-250,521-526).
+ * mode 0: nearest; 1: bilinear, align_corners=False.  Every sample is a
+ * vector of CI contiguous floats (1 for planar images, 2 for (..,H,W,2)
+ * flows); s_x / s_y / s_plane are strides in floats. */
+int mt_resize_fwd(const float* src, int64_t s_plane, int64_t s_y, int64_t s_x,
+                  int32_t NP, int32_t H, int32_t W, float* dst, int64_t d_plane,
+                  int64_t d_y, int64_t d_x, int32_t Ho, int32_t Wo, int32_t CI,
+                  int32_t mode, void* stream);
+/* backward of the bilinear mode: dsrc must be zero-filled by the caller */
+int mt_resize_bilinear_bwd(const float* ddst, int64_t d_plane, int64_t d_y,
+                           int64_t d_x, int32_t NP, int32_t Ho, int32_t Wo,
+                           float* dsrc, int64_t s_plane, int64_t s_y, int64_t s_x,
+                           int32_t H, int32_t W, int32_t CI, void* stream);
+
+/* Masked / weighted L1 reductions (LossesUtils.masked_l1 utils.py:138-169,
+ * F.l1_loss model_dfpn.py:257, utils.py:188-189).
+ *   acc[0] += sum_i w[b(i)] * | a_i*m_i - b_i*m_i |
+ *   acc[1] += sum over the mask tensor of w[b]*m      (if count_mask)
+ * data is [B][C][S], mask [B][MC][S] with MC in {1, C} (or NULL = ones),
+ * w is [B] (or NULL = ones).  `acc` must be zeroed by the caller. */
+int mt_l1_fwd(const float* a, const float* b, const float* mask, const float* w,
+              int32_t B, int32_t C, int32_t MC, int64_t S, int32_t count_mask,
+              float* acc, void* stream);
+/* da_i = sa * scale[0] * w[b] * sign(a_i*m_i - b_i*m_i) * m_i   (if da)
+ * db_i = -(same with sb)                                      (if db)  */
+int mt_l1_bwd(const float* a, const float* b, const float* mask, const float* w,
+              int32_t B, int32_t C, int32_t MC, int64_t S, const float* scale,
+              float* da, float* db, int32_t accumulate, void* stream);
+/* Sobel-gradient L1 (LossesUtils.grad utils.py:193-224) on planes [NP][H][W]:
+ * acc[0] += sum |sobel_h(a)-sobel_h(b)| + |sobel_v(a)-sobel_v(b)| */
+int mt_sobel_l1_fwd(const float* a, const float* b, int32_t NP, int32_t H,
+                    int32_t W, float* acc, void* stream);
+int mt_sobel_l1_bwd(const float* a, const float* b, int32_t NP, int32_t H,
+                    int32_t W, const float* scale, float* da, void* stream);
+
+/* Adam (torch.optim.Adam defaults; model_dfpn.py:302, model_chn.py:385) over a
+ * flat parameter range. step_size = lr/bias_correction1,
+ * inv_bc2_sqrt = 1/sqrt(bias_correction2). */
+int mt_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                 float beta1, float beta2, float step_size, float inv_bc2_sqrt,
+                 float eps, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MT355_H */

@@ -1,0 +1,43 @@
+"""Build libmt355.so (the C-ABI HIP library) in-tree with hipcc for gfx950."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libmt355.so')
+SOURCES = [('conv.hip', []), ('stream.hip', ['-ffp-contract=off']), ('api.cpp', [])]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(ROOT, 'include', 'mt355.h')]
+    objs = []
+    for src, extra in SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
+        objs.append(obj)
+        if force or _stale(obj, [path] + headers):
+            cmd = [hipcc, '-x', 'hip', '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17',
+                   '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-c', path, '-o', obj] + extra
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

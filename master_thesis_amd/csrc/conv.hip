@@ -1,0 +1,599 @@
+// Implicit-GEMM convolution engine for gfx950 (MI355X): forward / backward-data
+// (one kernel, two gather modes) and weight-gradient, on fp32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate, 64 FLOP/clk/SIMD).
+//
+// Replaces the F.conv2d / F.conv_transpose2d call-sites of the reference and
+// their autograd backward (model_dfpn.py:596-605,638-660,686-711,
+// model_chn.py:522-535,602-606, model_vgg.py:40-41).
+//
+// GEMM view (forward / backward-data):  C[pixel][o] = sum_k A[pixel][k] * Wt[o][k],
+// k = (kh, kw, c) flattened, A gathered on the fly from an NHWC4 view.
+// Block = 256 threads = 4 waves; block tile BM x BN = (WGM*TM*32) x (WGN*TN*32),
+// BK = 32.  A and B tiles are staged global -> registers -> LDS (double
+// buffered, one barrier per K step); every lane reads its MFMA operands with
+// ds_read_b128 (lane half h owns k = 8q+4h .. 8q+4h+3, so MFMA j of a group of
+// four consumes the k-pair {8q+j, 8q+4+j}); LDS rows are padded to 36 floats,
+// which keeps the b128 reads conflict-free.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;
+
+struct ConvK {
+  const float* x; long xsn, xsh, xsw; int H, W, C;   // physical dims of the gathered tensor
+  int xni; long xsg; int yni; long ysg;              // two-level image index of x and y
+  const float* wt; const float* bias;
+  float* y; long ysn, ysh, ysw; int Ho, Wo, Co;
+  int N, KH, KW, stride, pad, transposed, ups;
+  int M, K;
+  int act; float alpha;
+  const float* res; long rsn, rsh, rsw; float beta;
+  const float* ds; long dsn, dsh, dsw; int dact, dact_c0;
+  int accumulate;
+  int zb, zdiv; long xz, wz, yz;   // batched GEMM over blockIdx.z (correlation)
+};
+
+template <int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(256) void igemm_kernel(ConvK p) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  constexpr int RA = BM / 32, RB = BN / 32;
+  __shared__ __attribute__((aligned(16))) float sA[2][BM * LDK];
+  __shared__ __attribute__((aligned(16))) float sB[2][BN * LDK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (p.zb > 1) {
+    const int z = blockIdx.z;
+    p.x += (long)(z / p.zdiv) * p.xz;
+    p.wt += (long)z * p.wz;
+    p.y += (long)z * p.yz;
+  }
+
+  // ---- per-thread staging coordinates -----------------------------------
+  const int col4 = tid & 7;        // which float4 of the 32-wide k slice
+  const int row0 = tid >> 3;       // 0..31
+  long a_off[RA];
+  int a_oy[RA], a_ox[RA];
+  bool a_ok[RA];
+  const int HWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    int m = m0 + row0 + 32 * i;
+    a_ok[i] = m < p.M;
+    int mm = a_ok[i] ? m : 0;
+    int n = mm / HWo;
+    int r = mm - n * HWo;
+    a_oy[i] = r / p.Wo;
+    a_ox[i] = r - a_oy[i] * p.Wo;
+    a_off[i] = (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
+  }
+  // (kh, kw, c) of this thread's float4 inside the current k tile
+  int kc = col4 * 4, kkh = 0, kkw = 0;
+  while (kc >= p.C) { kc -= p.C; if (++kkw == p.KW) { kkw = 0; ++kkh; } }
+  const int HL = p.H << p.ups, WL = p.W << p.ups;
+  const int smask = p.stride - 1, sshift = p.stride >> 1;  // stride in {1,2}
+
+  f32x4 ra[RA], rb[RB];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      bool ok = a_ok[i] && kkh < p.KH;
+      int iy, ix;
+      if (!p.transposed) {
+        iy = a_oy[i] * p.stride - p.pad + kkh;
+        ix = a_ox[i] * p.stride - p.pad + kkw;
+        ok = ok && (unsigned)iy < (unsigned)HL && (unsigned)ix < (unsigned)WL;
+      } else {
+        int ty = a_oy[i] + p.pad - kkh, tx = a_ox[i] + p.pad - kkw;
+        ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & smask) == 0;
+        iy = ty >> sshift; ix = tx >> sshift;
+        ok = ok && iy < HL && ix < WL;
+      }
+      iy >>= p.ups; ix >>= p.ups;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(p.x + a_off[i] + (long)iy * p.xsh + (long)ix * p.xsw + kc);
+      ra[i] = v;
+    }
+    const int k = kt * BK + col4 * 4;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int n = n0 + row0 + 32 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n < p.Co && k < p.K) v = *reinterpret_cast<const f32x4*>(p.wt + (long)n * p.K + k);
+      rb[i] = v;
+    }
+    // advance (kh, kw, c) by BK for the next tile
+    kc += BK;
+    while (kc >= p.C) { kc -= p.C; if (++kkw == p.KW) { kkw = 0; ++kkh; } }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+      *reinterpret_cast<f32x4*>(&sA[buf][(row0 + 32 * i) * LDK + col4 * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+      *reinterpret_cast<f32x4*>(&sB[buf][(row0 + 32 * i) * LDK + col4 * 4]) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const float* A = &sA[buf][(wm * TM * 32 + li) * LDK + 4 * lh];
+    const float* B = &sB[buf][(wn * TN * 32 + li) * LDK + 4 * lh];
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const f32x4*>(A + a * 32 * LDK + q * 8);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const f32x4*>(B + b * 32 * LDK + q * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue -----------------------------------------------------------
+  // C/D layout of the 32x32 tile: col (o) = lane & 31, row (pixel) =
+  // (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= p.M) continue;
+      const int n = m / HWo;
+      const int rem = m - n * HWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const long yo = (long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + (long)oy * p.ysh + (long)ox * p.ysw;
+      const long ro = p.res ? (long)n * p.rsn + (long)oy * p.rsh + (long)ox * p.rsw : 0;
+      const long so = p.ds ? (long)n * p.dsn + (long)oy * p.dsh + (long)ox * p.dsw : 0;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int o = n0 + wn * TN * 32 + b * 32 + li;
+        if (o >= p.Co) continue;
+        float v = acc[a][b][r];
+        if (p.bias) v += p.bias[o];
+        v = mt_act_fn(v, p.act) * p.alpha;
+        if (p.res) v += p.beta * p.res[ro + o];
+        if (p.accumulate) v += p.y[yo + o];
+        if (p.ds && o >= p.dact_c0) v *= mt_dact_fn(p.ds[so + o], p.dact);
+        p.y[yo + o] = v;
+      }
+    }
+  }
+}
+
+// one thread per output element; the self-check restatement of the above
+__global__ void conv_naive_kernel(ConvK p) {
+  long total = (long)p.M * p.Co;
+  const int HWo = p.Ho * p.Wo;
+  const int HL = p.H << p.ups, WL = p.W << p.ups;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int o = (int)(e % p.Co);
+    int m = (int)(e / p.Co);
+    int n = m / HWo, rem = m - n * HWo, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    float acc = 0.f;
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw) {
+        int iy, ix;
+        if (!p.transposed) {
+          iy = oy * p.stride - p.pad + kh; ix = ox * p.stride - p.pad + kw;
+          if (iy < 0 || ix < 0 || iy >= HL || ix >= WL) continue;
+        } else {
+          int ty = oy + p.pad - kh, tx = ox + p.pad - kw;
+          if (ty < 0 || tx < 0 || ty % p.stride || tx % p.stride) continue;
+          iy = ty / p.stride; ix = tx / p.stride;
+          if (iy >= HL || ix >= WL) continue;
+        }
+        iy >>= p.ups; ix >>= p.ups;
+        const float* xp = p.x + (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn + (long)iy * p.xsh + (long)ix * p.xsw;
+        const float* wp = p.wt + (long)o * p.K + (long)(kh * p.KW + kw) * p.C;
+        for (int c = 0; c < p.C; ++c) acc = fmaf(xp[c], wp[c], acc);
+      }
+    float v = acc;
+    if (p.bias) v += p.bias[o];
+    v = mt_act_fn(v, p.act) * p.alpha;
+    if (p.res) v += p.beta * p.res[(long)n * p.rsn + (long)oy * p.rsh + (long)ox * p.rsw + o];
+    float* yp = p.y + (long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + (long)oy * p.ysh + (long)ox * p.ysw + o;
+    if (p.accumulate) v += *yp;
+    if (p.ds && o >= p.dact_c0) v *= mt_dact_fn(p.ds[(long)n * p.dsn + (long)oy * p.dsh + (long)ox * p.dsw + o], p.dact);
+    *yp = v;
+  }
+}
+
+int fill_convk(const mt_conv* d, ConvK* k) {
+  MT_REQUIRE(d, "mt_conv: null descriptor");
+  MT_REQUIRE(mt_view_ok(&d->x) && mt_view_ok(&d->y), "mt_conv: x/y view invalid (need 16B-aligned pointer, C%%4==0, strides%%4==0)");
+  MT_REQUIRE(d->wt && (reinterpret_cast<uintptr_t>(d->wt) & 15) == 0, "mt_conv: weights null/unaligned");
+  MT_REQUIRE(d->stride == 1 || d->stride == 2, "mt_conv: stride must be 1 or 2 (got %d)", d->stride);
+  MT_REQUIRE(d->KH > 0 && d->KW > 0 && d->pad >= 0 && d->ups >= 0 && d->ups <= 2, "mt_conv: bad kernel/pad/ups");
+  MT_REQUIRE(d->ups == 0 || (d->stride == 1 && !d->transposed), "mt_conv: ups needs stride 1, non-transposed");
+  MT_REQUIRE(d->x.N == d->y.N, "mt_conv: batch mismatch %d vs %d", d->x.N, d->y.N);
+  const int HL = d->x.H << d->ups, WL = d->x.W << d->ups;
+  if (!d->transposed) {
+    int ho = (HL + 2 * d->pad - d->KH) / d->stride + 1, wo = (WL + 2 * d->pad - d->KW) / d->stride + 1;
+    MT_REQUIRE(ho == d->y.H && wo == d->y.W, "mt_conv: output %dx%d does not match conv geometry %dx%d", d->y.H, d->y.W, ho, wo);
+  } else {
+    // y is the larger tensor: conv(y) must map back onto x's logical size
+    int hi = (d->y.H + 2 * d->pad - d->KH) / d->stride + 1, wi = (d->y.W + 2 * d->pad - d->KW) / d->stride + 1;
+    MT_REQUIRE(hi == HL && wi == WL, "mt_conv(transposed): y %dx%d is not a pre-image of x %dx%d", d->y.H, d->y.W, HL, WL);
+  }
+  MT_REQUIRE((int64_t)d->y.N * d->y.H * d->y.W < (1ll << 31), "mt_conv: too many pixels");
+  if (d->res.p) MT_REQUIRE(mt_view_flat(&d->res) && d->res.C >= d->y.C, "mt_conv: residual view invalid");
+  if (d->dsrc.p) MT_REQUIRE(mt_view_flat(&d->dsrc) && d->dsrc.C >= d->y.C, "mt_conv: dsrc view invalid");
+  k->xni = d->x.n_in; k->xsg = d->x.sg; k->yni = d->y.n_in; k->ysg = d->y.sg;
+  k->x = d->x.p; k->xsn = d->x.sn; k->xsh = d->x.sh; k->xsw = d->x.sw; k->H = d->x.H; k->W = d->x.W; k->C = d->x.C;
+  k->wt = d->wt; k->bias = d->bias;
+  k->y = d->y.p; k->ysn = d->y.sn; k->ysh = d->y.sh; k->ysw = d->y.sw; k->Ho = d->y.H; k->Wo = d->y.W; k->Co = d->y.C;
+  k->N = d->x.N; k->KH = d->KH; k->KW = d->KW; k->stride = d->stride; k->pad = d->pad; k->transposed = d->transposed; k->ups = d->ups;
+  k->M = d->y.N * d->y.H * d->y.W; k->K = d->KH * d->KW * d->x.C;
+  k->act = d->act; k->alpha = d->alpha;
+  k->res = d->res.p; k->rsn = d->res.sn; k->rsh = d->res.sh; k->rsw = d->res.sw; k->beta = d->beta;
+  k->ds = d->dsrc.p; k->dsn = d->dsrc.sn; k->dsh = d->dsrc.sh; k->dsw = d->dsrc.sw; k->dact = d->dact; k->dact_c0 = d->dact_c0;
+  k->accumulate = d->accumulate;
+  k->zb = 1; k->zdiv = 1; k->xz = k->wz = k->yz = 0;
+  return MT_OK;
+}
+
+template <int WGM, int WGN, int TM, int TN>
+void launch_igemm(const ConvK& k, hipStream_t s) {
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  dim3 grid((k.M + BM - 1) / BM, (k.Co + BN - 1) / BN, k.zb);
+  hipLaunchKernelGGL((igemm_kernel<WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
+}
+
+// ------------------------------------------------------------------ wgrad --
+struct WgK {
+  const float* d; long dsn, dsh, dsw; int Hd, Wd, Cd;
+  const float* g; long gsn, gsh, gsw; int Hg, Wg, Cg;
+  int dni; long dsg; int gni; long gsg;
+  int KH, KW, stride, pad, ups;
+  int M, per_split;   // pixels, pixels per split (multiple of 32)
+  int atiles, btiles;
+  float* slabs;
+};
+
+// dW[a][tap][b] partial over one pixel range.  GEMM with K = pixels: both
+// operands are pixel-major, so LDS tiles are [32 pixels][channels] and the
+// MFMA operands (one f32 per lane) are read with conflict-free ds_read_b32.
+template <int WGM, int WGN, int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgK p) {
+  constexpr int BMA = WGM * TM * 32, BNB = WGN * TN * 32;
+  constexpr int LDA = BMA + 4, LDB = BNB + 4;
+  constexpr int FA = BMA / 4, FB = BNB / 4;          // float4 per pixel row
+  constexpr int PA = 256 / FA, PB = 256 / FB;        // pixel rows per pass
+  constexpr int RA = 32 / PA, RB = 32 / PB;
+  __shared__ __attribute__((aligned(16))) float sD[2][32 * LDA];
+  __shared__ __attribute__((aligned(16))) float sG[2][32 * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN, li = lane & 31, lh = lane >> 5;
+  int bid = blockIdx.x;
+  const int bt = bid % p.btiles; bid /= p.btiles;
+  const int at = bid % p.atiles; bid /= p.atiles;
+  const int tap = bid;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int a0 = at * BMA, b0 = bt * BNB;
+  const int split = blockIdx.y;
+  const int pbeg = split * p.per_split;
+  const int pend = min(p.M, pbeg + p.per_split);
+  const int HWd = p.Hd * p.Wd;
+  const int HL = p.Hg << p.ups, WL = p.Wg << p.ups;
+
+  const int acol = (tid % FA) * 4, arow = tid / FA;
+  const int bcol = (tid % FB) * 4, brow = tid / FB;
+  f32x4 rd[RA], rg[RB];
+  auto load_chunk = [&](int pix0) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int pidx = pix0 + arow + PA * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pidx < pend && a0 + acol < p.Cd) {
+        int n = pidx / HWd, rem = pidx - n * HWd, y = rem / p.Wd, x = rem - y * p.Wd;
+        v = *reinterpret_cast<const f32x4*>(p.d + (long)(n / p.dni) * p.dsg + (long)(n % p.dni) * p.dsn + (long)y * p.dsh + (long)x * p.dsw + a0 + acol);
+      }
+      rd[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int pidx = pix0 + brow + PB * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pidx < pend && b0 + bcol < p.Cg) {
+        int n = pidx / HWd, rem = pidx - n * HWd, y = rem / p.Wd, x = rem - y * p.Wd;
+        int iy = y * p.stride - p.pad + kh, ix = x * p.stride - p.pad + kw;
+        if ((unsigned)iy < (unsigned)HL && (unsigned)ix < (unsigned)WL) {
+          iy >>= p.ups; ix >>= p.ups;
+          v = *reinterpret_cast<const f32x4*>(p.g + (long)(n / p.gni) * p.gsg + (long)(n % p.gni) * p.gsn + (long)iy * p.gsh + (long)ix * p.gsw + b0 + bcol);
+        }
+      }
+      rg[i] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&sD[buf][(arow + PA * i) * LDA + acol]) = rd[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&sG[buf][(brow + PB * i) * LDB + bcol]) = rg[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunks = pend > pbeg ? (pend - pbeg + 31) / 32 : 0;
+  if (nchunks > 0) {
+    load_chunk(pbeg);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunks) load_chunk(pbeg + (ch + 1) * 32);
+    const float* A = &sD[buf][lh * LDA + wm * TM * 32 + li];
+    const float* B = &sG[buf][lh * LDB + wn * TN * 32 + li];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float fa[TM], fb[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[a] = A[2 * j * LDA + a * 32];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[b] = B[2 * j * LDB + b * 32];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+    if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+  const int T = p.KH * p.KW;
+  float* slab = p.slabs + (long)split * p.Cd * T * p.Cg;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ai = a0 + wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ai >= p.Cd) continue;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int bi = b0 + wn * TN * 32 + b * 32 + li;
+        if (bi < p.Cg) slab[((long)ai * T + tap) * p.Cg + bi] = acc[a][b][r];
+      }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* slabs, int splits, int AP, int T, int BP, float* dst,
+                                    int A, int B, long sa, long sb, long st, int accumulate) {
+  const long per = (long)AP * T * BP;
+  const long total = (long)A * T * B;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int b = (int)(e % B);
+    long r = e / B;
+    int t = (int)(r % T);
+    int a = (int)(r / T);
+    const float* s = slabs + ((long)a * T + t) * BP + b;
+    float acc = 0.f;
+    for (int i = 0; i < splits; ++i) acc += s[i * per];
+    float* d = dst + a * sa + b * sb + t * st;
+    *d = accumulate ? *d + acc : acc;
+  }
+}
+
+__global__ void bias_grad_partial_kernel(const float* d, long dsn, long dsh, long dsw, int Hd, int Wd, int CP,
+                                         int M, float* ws) {
+  // block b sums pixels [b*chunk, ...) for every channel; thread t owns channel t % CP rows t / CP
+  const int C4 = CP / 4;
+  const int rows = blockDim.x / C4;
+  const int c4 = threadIdx.x % C4, r = threadIdx.x / C4;
+  const int HW = Hd * Wd;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (r < rows)
+    for (long pix = (long)blockIdx.x * rows + r; pix < M; pix += (long)gridDim.x * rows) {
+      int n = (int)(pix / HW), rem = (int)(pix - (long)n * HW), y = rem / Wd, x = rem - y * Wd;
+      acc += *reinterpret_cast<const f32x4*>(d + (long)n * dsn + (long)y * dsh + (long)x * dsw + c4 * 4);
+    }
+  extern __shared__ float sm[];   // [rows][CP]
+  if (r < rows) *reinterpret_cast<f32x4*>(&sm[r * CP + c4 * 4]) = acc;
+  __syncthreads();
+  for (int c = threadIdx.x; c < CP; c += blockDim.x) {
+    float s = 0.f;
+    for (int i = 0; i < rows; ++i) s += sm[i * CP + c];
+    ws[(long)blockIdx.x * CP + c] = s;
+  }
+}
+
+__global__ void bias_grad_final_kernel(const float* ws, int nblk, int CP, float* db, int C, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int i = 0; i < nblk; ++i) s += ws[(long)i * CP + c];
+  db[c] = accumulate ? db[c] + s : s;
+}
+
+__global__ void weight_pack_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, float* dst,
+                                   int AP, int BP) {
+  const long total = (long)AP * T * BP;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int b = (int)(e % BP);
+    long r = e / BP;
+    int t = (int)(r % T);
+    int a = (int)(r / T);
+    dst[e] = (a < A && b < B) ? src[a * sa + b * sb + t * st] : 0.f;
+  }
+}
+
+__global__ void pad_vector_kernel(const float* src, int n, float* dst, int np) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < np) dst[i] = i < n ? src[i] : 0.f;
+}
+
+int wgrad_cfg(const mt_wgrad* d, int* atiles, int* btiles, int* cfg) {
+  // pick the block tile from the channel counts
+  const int cd = d->d.C, cg = d->g.C;
+  if (cd > 64 && cg > 64) { *cfg = 0; *atiles = (cd + 127) / 128; *btiles = (cg + 127) / 128; }        // 128 x 128
+  else if (cd <= 32) { *cfg = 2; *atiles = 1; *btiles = (cg + 127) / 128; }                             // 32 x 128
+  else if (cg <= 32) { *cfg = 3; *atiles = (cd + 127) / 128; *btiles = 1; }                             // 128 x 32
+  else { *cfg = 1; *atiles = (cd + 63) / 64; *btiles = (cg + 63) / 64; }                                // 64 x 64
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mt_conv_run(const mt_conv* d, void* stream) {
+  ConvK k;
+  int rc = fill_convk(d, &k);
+  if (rc) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (k.Co > 64) launch_igemm<2, 2, 2, 2>(k, s);        // 128 x 128
+  else if (k.Co > 32) launch_igemm<2, 2, 2, 1>(k, s);   // 128 x 64
+  else launch_igemm<4, 1, 1, 1>(k, s);                  // 128 x 32
+  return mt_check_launch("mt_conv_run");
+}
+
+extern "C" int mt_conv_run_naive(const mt_conv* d, void* stream) {
+  ConvK k;
+  int rc = fill_convk(d, &k);
+  if (rc) return rc;
+  hipLaunchKernelGGL(conv_naive_kernel, dim3(mt_grid_1d((int64_t)k.M * k.Co, 256, 65535)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), k);
+  return mt_check_launch("mt_conv_run_naive");
+}
+
+extern "C" int64_t mt_wgrad_slab_floats(const mt_wgrad* d) {
+  if (!d) return 0;
+  return (int64_t)d->splits * d->d.C * d->KH * d->KW * d->g.C;
+}
+
+extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
+  MT_REQUIRE(d && mt_view_ok(&d->d) && mt_view_ok(&d->g), "mt_wgrad: invalid views");
+  MT_REQUIRE(d->slabs && d->splits >= 1, "mt_wgrad: slabs/splits");
+  MT_REQUIRE(d->stride == 1 || d->stride == 2, "mt_wgrad: stride must be 1 or 2");
+  MT_REQUIRE(d->d.N == d->g.N, "mt_wgrad: batch mismatch");
+  const int HL = d->g.H << d->ups, WL = d->g.W << d->ups;
+  MT_REQUIRE((HL + 2 * d->pad - d->KH) / d->stride + 1 == d->d.H && (WL + 2 * d->pad - d->KW) / d->stride + 1 == d->d.W,
+             "mt_wgrad: dense tensor %dx%d is not conv(gathered %dx%d)", d->d.H, d->d.W, HL, WL);
+  MT_REQUIRE((int64_t)d->d.N * d->d.H * d->d.W < (1ll << 31), "mt_wgrad: too many pixels");
+  WgK k;
+  k.d = d->d.p; k.dsn = d->d.sn; k.dsh = d->d.sh; k.dsw = d->d.sw; k.Hd = d->d.H; k.Wd = d->d.W; k.Cd = d->d.C;
+  k.g = d->g.p; k.gsn = d->g.sn; k.gsh = d->g.sh; k.gsw = d->g.sw; k.Hg = d->g.H; k.Wg = d->g.W; k.Cg = d->g.C;
+  k.dni = d->d.n_in; k.dsg = d->d.sg; k.gni = d->g.n_in; k.gsg = d->g.sg;
+  k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.ups = d->ups;
+  k.M = d->d.N * d->d.H * d->d.W;
+  int per = (k.M + d->splits - 1) / d->splits;
+  k.per_split = ((per + 31) / 32) * 32;
+  MT_REQUIRE((int64_t)k.per_split * d->splits >= k.M, "mt_wgrad: split arithmetic");
+  k.slabs = d->slabs;
+  int cfg;
+  wgrad_cfg(d, &k.atiles, &k.btiles, &cfg);
+  dim3 grid(k.atiles * k.btiles * d->KH * d->KW, d->splits);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (cfg) {
+    case 0: hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, k); break;
+    case 1: hipLaunchKernelGGL((wgrad_kernel<2, 2, 1, 1>), grid, dim3(256), 0, s, k); break;
+    case 2: hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 1>), grid, dim3(256), 0, s, k); break;
+    default: hipLaunchKernelGGL((wgrad_kernel<4, 1, 1, 1>), grid, dim3(256), 0, s, k); break;
+  }
+  return mt_check_launch("mt_wgrad_run");
+}
+
+extern "C" int mt_wgrad_reduce(const float* slabs, int32_t splits, int32_t AP, int32_t T, int32_t BP, float* dst,
+                               int32_t A, int32_t B, int64_t sa, int64_t sb, int64_t st, int32_t accumulate,
+                               void* stream) {
+  MT_REQUIRE(slabs && dst && splits >= 1 && A <= AP && B <= BP, "mt_wgrad_reduce: bad arguments");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mt_grid_1d((int64_t)A * T * B, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), slabs, splits, AP, T, BP, dst, A, B, (long)sa, (long)sb,
+                     (long)st, accumulate);
+  return mt_check_launch("mt_wgrad_reduce");
+}
+
+extern "C" int mt_bias_grad(const mt_view* d, float* db, int32_t C, float* ws, int32_t accumulate, void* stream) {
+  MT_REQUIRE(mt_view_flat(d) && db && ws && C <= d->C, "mt_bias_grad: bad arguments");
+  MT_REQUIRE(d->C <= 1024, "mt_bias_grad: too many channels");
+  const int M = d->N * d->H * d->W;
+  const int C4 = d->C / 4;
+  const int rows = 256 / C4 > 0 ? 256 / C4 : 1;
+  const int threads = rows * C4;
+  int nblk = (M + rows * 8 - 1) / (rows * 8);
+  if (nblk > 256) nblk = 256;
+  if (nblk < 1) nblk = 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(nblk), dim3(threads), rows * d->C * sizeof(float), s, d->p,
+                     (long)d->sn, (long)d->sh, (long)d->sw, d->H, d->W, d->C, M, ws);
+  hipLaunchKernelGGL(bias_grad_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, nblk, d->C, db, C, accumulate);
+  return mt_check_launch("mt_bias_grad");
+}
+
+extern "C" int mt_weight_pack(const float* src, int32_t A, int32_t B, int32_t T, int64_t sa, int64_t sb, int64_t st,
+                              float* dst, int32_t AP, int32_t BP, void* stream) {
+  MT_REQUIRE(src && dst && A <= AP && B <= BP && (BP & 3) == 0, "mt_weight_pack: bad arguments");
+  hipLaunchKernelGGL(weight_pack_kernel, dim3(mt_grid_1d((int64_t)AP * T * BP, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, A, B, T, (long)sa, (long)sb, (long)st, dst, AP, BP);
+  return mt_check_launch("mt_weight_pack");
+}
+
+extern "C" int mt_pad_vector(const float* src, int32_t n, float* dst, int32_t np, void* stream) {
+  MT_REQUIRE(src && dst && n <= np, "mt_pad_vector: bad arguments");
+  hipLaunchKernelGGL(pad_vector_kernel, dim3((np + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), src,
+                     n, dst, np);
+  return mt_check_launch("mt_pad_vector");
+}
+
+extern "C" int mt_rownorm(const mt_view* x, const float* v, float* out, void* stream);
+
+// CorrelationVGG.correlation_masked_4d (model_dfpn.py:534-565): masked L2 row
+// normalisation of both feature sets, then one 256x256x512 NT GEMM per
+// (clip, reference) pair, batched over blockIdx.z.
+extern "C" int mt_corr_masked(const mt_view* ft, const mt_view* fr, const float* vt, const float* vr, int32_t B,
+                              int32_t R, float* out, float* ws, void* stream) {
+  MT_REQUIRE(mt_view_ok(ft) && mt_view_ok(fr) && out && ws, "mt_corr_masked: bad arguments");
+  MT_REQUIRE(ft->N == B && fr->N == B * R && ft->H == fr->H && ft->W == fr->W && ft->C == fr->C,
+             "mt_corr_masked: feature geometry mismatch");
+  const int P = ft->H * ft->W, C = ft->C;
+  MT_REQUIRE((P & 3) == 0 && B * R < 65536, "mt_corr_masked: P %% 4 != 0 or too many pairs");
+  float* tn = ws;
+  float* rn = ws + (size_t)B * P * C;
+  int rc = mt_rownorm(ft, vt, tn, stream);
+  if (rc) return rc;
+  rc = mt_rownorm(fr, vr, rn, stream);
+  if (rc) return rc;
+  ConvK k = {};
+  k.xni = 1; k.xsg = 0; k.yni = 1; k.ysg = 0;
+  k.x = tn; k.xsn = 0; k.xsh = 0; k.xsw = C; k.H = 1; k.W = P; k.C = C;
+  k.wt = rn; k.bias = nullptr;
+  k.y = out; k.ysn = 0; k.ysh = 0; k.ysw = P; k.Ho = 1; k.Wo = P; k.Co = P;
+  k.N = 1; k.KH = 1; k.KW = 1; k.stride = 1; k.pad = 0; k.transposed = 0; k.ups = 0;
+  k.M = P; k.K = C;
+  k.act = MT_ACT_NONE; k.alpha = 1.f;
+  k.zb = B * R; k.zdiv = R; k.xz = (long)P * C; k.wz = (long)P * C; k.yz = (long)P * P;
+  launch_igemm<2, 2, 2, 1>(k, static_cast<hipStream_t>(stream));
+  return mt_check_launch("mt_corr_masked");
+}

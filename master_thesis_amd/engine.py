@@ -1,0 +1,339 @@
+"""Host side of the convolution engine: NHWC4 tensors, weight packing and the
+autograd nodes that chain the C-ABI kernels (mt_conv_run / mt_wgrad_run / ...).
+
+Activations inside the engine are float32 torch tensors of shape (N, H, W, Cp)
+with Cp = channels padded to a multiple of 4 (padding holds zeros).  Every
+heavy op is a libmt355 call on the current HIP stream; torch only owns memory
+and the autograd graph.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+WEIGHT_EPOCH = 0          # bumped by the optimizer: packed-weight cache key
+_pack_cache = {}
+
+
+def bump_weight_epoch():
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+    _pack_cache.clear()
+
+
+def cpad(c):
+    return (c + 3) // 4 * 4
+
+
+def view_of(t):
+    """mt_view of a 4-D (N,H,W,C) tensor whose channel stride is 1 (a channel
+    window of a wider NHWC buffer is fine)."""
+    assert t.dim() == 4 and t.stride(3) == 1 and t.dtype == torch.float32, (t.shape, t.stride())
+    n, h, w, c = t.shape
+    return L.View(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2), n, h, w, c, n, 0)
+
+
+def swap_view(t, groups):
+    """SeparableConv4d's permute (model_dfpn.py:621-623) as addressing: ``t`` is
+    (G*P1, h, w, C) = [g][p1][p2][c]; the result views it as G*P2 images
+    (g, p2) whose h x w pixels run over p1 (needs P1 == P2 == h*w)."""
+    n, h, w, c = t.shape
+    assert t.is_contiguous()
+    p1 = n // groups
+    p2 = h * w
+    assert p1 * groups == n and p1 == p2
+    return L.View(t.data_ptr(), c, w * p2 * c, p2 * c, groups * p2, h, w, c, p2, p1 * p2 * c)
+
+
+def null_view():
+    return L.View(0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+
+
+# ------------------------------------------------------------ weight packs --
+def _pack(w, a_dim, kind):
+    """[AP][T][BP] packed copy of a conv weight.  ``a_dim`` selects which of
+    the two leading dims of ``w`` becomes the GEMM's output-channel axis."""
+    key = (w.data_ptr(), w._version, kind, WEIGHT_EPOCH)
+    hit = _pack_cache.get(key)
+    if hit is not None:
+        return hit[0]
+    d0, d1, kh, kw = w.shape
+    t = kh * kw
+    assert w.is_contiguous()
+    if a_dim == 0:
+        a, b, sa, sb = d0, d1, d1 * t, t
+    else:
+        a, b, sa, sb = d1, d0, t, d1 * t
+    out = torch.empty((cpad(a), t, cpad(b)), device=w.device, dtype=torch.float32)
+    L.call('mt_weight_pack', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), L.stream_ptr())
+    # the entry keeps ``w`` alive so that its address cannot be recycled for a
+    # different weight while the key is valid (cleared every optimizer step)
+    _pack_cache[key] = (out, w)
+    return out
+
+
+def _pad_bias(b, n):
+    if b is None:
+        return None
+    key = (b.data_ptr(), b._version, 'bias', WEIGHT_EPOCH)
+    hit = _pack_cache.get(key)
+    if hit is not None:
+        return hit[0]
+    out = torch.empty((cpad(n),), device=b.device, dtype=torch.float32)
+    L.call('mt_pad_vector', L.ptr(b), n, L.ptr(out), cpad(n), L.stream_ptr())
+    _pack_cache[key] = (out, b)
+    return out
+
+
+class LayerSpec:
+    """One conv-shaped layer.  kind 'c' = Conv2d (weight O,I,k,k), 't' =
+    ConvTranspose2d (weight I,O,k,k, output_padding 1).  ``ups``: the input is
+    nearest-upsampled x2 first (RRDBNet).  ``swap_groups``: the input is the
+    previous output seen through ``swap_view``."""
+
+    def __init__(self, kind, cin, cout, k, stride=1, act=L.ACT_NONE, ups=0, swap_groups=0):
+        self.kind, self.cin, self.cout, self.k = kind, cin, cout, k
+        self.stride, self.pad, self.act, self.ups = stride, k // 2, act, ups
+        self.swap_groups = swap_groups
+
+    def out_hw(self, h, w):
+        h, w = h << self.ups, w << self.ups
+        if self.kind == 'c':
+            return ((h + 2 * self.pad - self.k) // self.stride + 1,
+                    (w + 2 * self.pad - self.k) // self.stride + 1)
+        return ((h - 1) * self.stride - 2 * self.pad + self.k + 1,
+                (w - 1) * self.stride - 2 * self.pad + self.k + 1)
+
+
+def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.0):
+    """Run one layer forward.  xv: mt_view of the input; x_shape (N,H,W)."""
+    n, h, w_ = x_shape
+    ho, wo = spec.out_hw(h, w_)
+    if out is None:
+        out = torch.empty((n, ho, wo, cpad(spec.cout)), device=w.device, dtype=torch.float32)
+    d = L.Conv()
+    d.x, d.y = xv, view_of(out)
+    d.wt = _pack(w, 0 if spec.kind == 'c' else 1, 'f').data_ptr()
+    pb = _pad_bias(b, spec.cout)
+    d.bias = pb.data_ptr() if pb is not None else None
+    d.KH = d.KW = spec.k
+    d.stride, d.pad, d.ups = spec.stride, spec.pad, spec.ups
+    d.transposed = 0 if spec.kind == 'c' else 1
+    d.act, d.alpha = spec.act, alpha
+    d.res = view_of(res) if res is not None else null_view()
+    d.beta = beta
+    d.dsrc = null_view()
+    L.call('mt_conv_run', C.byref(d), L.stream_ptr())
+    return out
+
+
+def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, accumulate=False, alpha=1.0):
+    """dIn = bwd-data(dZ) written through the view ``yv`` (the layer's input
+    geometry), optionally gated by act'(dsrc) (the previous layer's saved
+    output)."""
+    d = L.Conv()
+    d.x, d.y = view_of(dz), yv
+    d.wt = _pack(w, 1 if spec.kind == 'c' else 0, 'b').data_ptr()
+    d.bias = None
+    d.KH = d.KW = spec.k
+    d.stride, d.pad, d.ups = spec.stride, spec.pad, 0
+    d.transposed = 1 if spec.kind == 'c' else 0
+    d.act, d.alpha = L.ACT_NONE, alpha
+    d.res, d.beta = null_view(), 0.0
+    d.dsrc = view_of(dsrc) if dsrc is not None else null_view()
+    d.dact, d.dact_c0 = dact, dact_c0
+    d.accumulate = 1 if accumulate else 0
+    L.call('mt_conv_run', C.byref(d), L.stream_ptr())
+
+
+def _splits(blocks_base, pixels):
+    s = max(1, min((1536 + blocks_base - 1) // blocks_base, pixels // 512))
+    return max(1, min(s, 512))
+
+
+def conv_backward_weight(spec, dz, xin_view, w, need_bias=True):
+    """(dW, db) of one layer.  dz: (N,Ho,Wo,CoP) gradient wrt the layer's
+    pre-activation output; xin_view: mt_view of the layer's input."""
+    dzv = view_of(dz)
+    if spec.kind == 'c':
+        dv, gv, a, b = dzv, xin_view, spec.cout, spec.cin
+    else:
+        dv, gv, a, b = xin_view, dzv, spec.cin, spec.cout
+    ap, bp, t = cpad(a), cpad(b), spec.k * spec.k
+    # tiles as chosen by wgrad_cfg in conv.hip
+    if ap > 64 and bp > 64:
+        tiles = ((ap + 127) // 128) * ((bp + 127) // 128)
+    elif ap <= 32:
+        tiles = (bp + 127) // 128
+    elif bp <= 32:
+        tiles = (ap + 127) // 128
+    else:
+        tiles = ((ap + 63) // 64) * ((bp + 63) // 64)
+    pixels = dv.N * dv.H * dv.W
+    d = L.Wgrad()
+    d.d, d.g = dv, gv
+    d.KH = d.KW = spec.k
+    d.stride, d.pad = spec.stride, spec.pad
+    d.ups = spec.ups if spec.kind == 'c' else 0
+    d.splits = _splits(tiles * t, pixels)
+    slabs = torch.empty((d.splits * ap * t * bp,), device=w.device, dtype=torch.float32)
+    d.slabs = slabs.data_ptr()
+    L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
+    dw = torch.empty_like(w)
+    # both Conv2d (O,I,k,k) and ConvTranspose2d (I,O,k,k): a = dim 0, b = dim 1
+    L.call('mt_wgrad_reduce', L.ptr(slabs), d.splits, ap, t, bp, L.ptr(dw), a, b, b * t, t, 1, 0, L.stream_ptr())
+    db = None
+    if need_bias:
+        db = torch.empty((spec.cout,), device=w.device, dtype=torch.float32)
+        ws = torch.empty((256 * dz.shape[3],), device=w.device, dtype=torch.float32)
+        L.call('mt_bias_grad', C.byref(dzv), L.ptr(db), spec.cout, L.ptr(ws), 0, L.stream_ptr())
+    return dw, db
+
+
+def dact_(g, saved, act):
+    """g *= act'(saved), in place."""
+    if act != L.ACT_NONE:
+        gv = view_of(g)
+        L.call('mt_dact', C.byref(gv), C.byref(view_of(saved)), act, C.byref(gv), L.stream_ptr())
+    return g
+
+
+class ConvStackFn(torch.autograd.Function):
+    """A chain of conv-shaped layers (nn.Sequential of Conv2d / ConvTranspose2d
+    + ReLU in the reference: model_dfpn.py:596-605, 638-660, 686-711) as ONE
+    autograd node on NHWC4 tensors."""
+
+    @staticmethod
+    def forward(ctx, x, specs, *params):
+        assert x.is_contiguous() and x.dim() == 4
+        acts = [x]
+        cur = x
+        for i, sp in enumerate(specs):
+            assert sp.ups == 0
+            w, b = params[2 * i], params[2 * i + 1]
+            if sp.swap_groups:
+                xv = swap_view(cur, sp.swap_groups)
+                shape = (xv.N, xv.H, xv.W)
+            else:
+                xv, shape = view_of(cur), cur.shape[:3]
+            cur = conv_forward(sp, xv, shape, w, b)
+            acts.append(cur)
+        ctx.specs = specs
+        # Function.forward always runs with grad disabled: keep the saved
+        # activations only when something upstream needs a gradient
+        ctx.acts = acts if any(ctx.needs_input_grad) else None
+        ctx.save_for_backward(*params)
+        return cur
+
+    @staticmethod
+    def backward(ctx, dy):
+        specs, acts, params = ctx.specs, ctx.acts, ctx.saved_tensors
+        grads = [None] * len(params)
+        dz = dy.contiguous()
+        if specs[-1].act != L.ACT_NONE:
+            dz = dact_(dz.clone(), acts[-1], specs[-1].act)
+        need_x = ctx.needs_input_grad[0]
+        for i in range(len(specs) - 1, -1, -1):
+            sp, w = specs[i], params[2 * i]
+            xin = acts[i]
+            xin_view = swap_view(xin, sp.swap_groups) if sp.swap_groups else view_of(xin)
+            dw, db = conv_backward_weight(sp, dz, xin_view, w)
+            grads[2 * i], grads[2 * i + 1] = dw, db
+            if i == 0 and not need_x:
+                dz = None
+                break
+            dx = torch.empty_like(xin)
+            yv = swap_view(dx, sp.swap_groups) if sp.swap_groups else view_of(dx)
+            prev_act = specs[i - 1].act if i > 0 else L.ACT_NONE
+            if sp.swap_groups:
+                assert prev_act == L.ACT_NONE
+            conv_backward_data(sp, dz, w, yv, dsrc=xin if prev_act != L.ACT_NONE else None, dact=prev_act)
+            dz = dx
+            acts[i + 1] = None   # release the saved activation
+        return (dz, None) + tuple(grads)
+
+
+def conv_stack(x, specs, params):
+    return ConvStackFn.apply(x, specs, *params)
+
+
+# ------------------------------------------------------------ layout ops ---
+def to_nhwc4(x, scale=None, shift=None, cp=None):
+    """(N,C,H,W) (any strides) -> (N,H,W,Cp) with optional per-channel affine."""
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, cp or cpad(c)), device=x.device, dtype=torch.float32)
+    if out.shape[3] > cpad(c):
+        out.zero_()
+    ov = view_of(out)
+    L.call('mt_nchw_to_nhwc4', L.ptr(x), x.stride(0), x.stride(1), x.stride(2), x.stride(3), n, c, h, w,
+           L.ptr(scale), L.ptr(shift), C.byref(ov), 0, L.stream_ptr())
+    return out
+
+
+def from_nhwc4(x4, c, scale=None, shift=None):
+    n, h, w, _ = x4.shape
+    out = torch.empty((n, c, h, w), device=x4.device, dtype=torch.float32)
+    L.call('mt_nhwc4_to_nchw', C.byref(view_of(x4)), 0, L.ptr(out), out.stride(0), out.stride(1), out.stride(2),
+           out.stride(3), c, L.ptr(scale), L.ptr(shift), 0, L.stream_ptr())
+    return out
+
+
+def maxpool2x2(x4):
+    n, h, w, c = x4.shape
+    out = torch.empty((n, h // 2, w // 2, c), device=x4.device, dtype=torch.float32)
+    L.call('mt_maxpool2x2', C.byref(view_of(x4)), C.byref(view_of(out)), L.stream_ptr())
+    return out
+
+
+class ToNHWC4Fn(torch.autograd.Function):
+    """Differentiable (N,C,H,W) -> (N,H,W,Cp) layout change."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.c = x.shape[1]
+        return to_nhwc4(x)
+
+    @staticmethod
+    def backward(ctx, d4):
+        return from_nhwc4(d4.contiguous(), ctx.c)
+
+
+class FromNHWC4Fn(torch.autograd.Function):
+    """Differentiable (N,H,W,Cp) -> (N,C,H,W) layout change."""
+
+    @staticmethod
+    def forward(ctx, x4, c):
+        return from_nhwc4(x4.contiguous(), c)
+
+    @staticmethod
+    def backward(ctx, d):
+        return to_nhwc4(d), None
+
+
+def pack_images(out4, b, r, sources):
+    """Fill the NHWC4 tensor ``out4`` (B*R images) from (B,C,R,H,W)/(B,C,H,W)
+    tensors through mt_pack_pairs.  sources: (tensor, c_off, scale, shift)."""
+    n, h, w, _ = out4.shape
+    assert n == b * r
+    arr = (L.PackSrc * len(sources))()
+    keep = []
+    for i, (t, c_off, scale, shift) in enumerate(sources):
+        t = t.contiguous()
+        keep.append(t)
+        hw = h * w
+        if t.dim() == 5:
+            c = t.shape[1]
+            assert t.shape == (b, c, r, h, w)
+            arr[i] = L.PackSrc(t.data_ptr(), c * r * hw, hw, r * hw, w, 1, c, c_off,
+                               scale.data_ptr() if scale is not None else None,
+                               shift.data_ptr() if shift is not None else None)
+        else:
+            c = t.shape[1]
+            assert t.shape == (b, c, h, w)
+            arr[i] = L.PackSrc(t.data_ptr(), c * hw, 0, hw, w, 1, c, c_off,
+                               scale.data_ptr() if scale is not None else None,
+                               shift.data_ptr() if shift is not None else None)
+    ov = view_of(out4)
+    L.call('mt_pack_pairs', arr, len(sources), b, r, C.byref(ov), L.stream_ptr())
+    return out4

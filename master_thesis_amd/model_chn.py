@@ -1,0 +1,318 @@
+"""Copy-and-Hallucinate Network (CHN) on the mt355 HIP kernels.
+
+Drop-in for the training path of ``master_thesis/model_chn.py``: ``CHN``,
+``RRDBNet``, ``RRDB``, ``ResidualDenseBlock5C`` with the reference's constructor
+arguments, state-dict keys (``nn.conv_first.N``, ``nn.rrdb_trunk.K.rdbJ.convI``,
+``nn.{trunk_conv,upconv1,upconv2,hr_conv,conv_last}``) and loss names/order.
+The whole RRDBNet is ONE autograd node: dense-block concatenations are channel
+windows of a single 192-channel NHWC buffer (no torch.cat copies), residual
+scalings are fused into conv epilogues, and the backward accumulates the dense
+gradients in place.
+"""
+import ctypes as C
+import functools
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+from . import ops
+from .lightning_shim import LightningModule
+from .optim import FlatAdam
+from .utils import LossesUtils
+
+LRELU, NONE = L.ACT_LRELU, L.ACT_NONE
+
+
+def _axpby(x, a, z, b, out):
+    L.call('mt_axpby', C.byref(E.view_of(x)), a, C.byref(E.view_of(z)) if z is not None else None, b,
+           C.byref(E.view_of(out)), L.stream_ptr())
+    return out
+
+
+class RRDBNetFn(torch.autograd.Function):
+    """RRDBNet.forward (model_chn.py:538-555) and its backward on NHWC4."""
+
+    @staticmethod
+    def forward(ctx, x4, net, names, *params):
+        P = dict(zip(names, params))
+        nf, gc, nb = net.nf, net.gc, net.nb
+        cw = nf + 4 * gc
+        keep = any(ctx.needs_input_grad)
+        saved = {}
+
+        def conv(key, xin, cin, cout, stride=1, act=NONE, ups=0, out=None, res=None, alpha=1.0, beta=0.0):
+            sp = E.LayerSpec('c', cin, cout, 3, stride, act, ups)
+            return E.conv_forward(sp, E.view_of(xin), xin.shape[:3], P[key + '.weight'], P[key + '.bias'], out=out,
+                                  res=res, alpha=alpha, beta=beta)
+
+        # conv_first: five plain convs (two stride-2), no activation (:522-528)
+        cur, first = x4, [x4]
+        for i, s in enumerate((1, 1, 2, 1, 2)):
+            cur = conv(f'conv_first.{i}', cur, net.in_nc if i == 0 else nf, nf, stride=s)
+            first.append(cur)
+        f0 = cur
+        n, h, w, _ = f0.shape
+
+        def new_buf():
+            return torch.empty((n, h, w, cw), device=f0.device, dtype=torch.float32)
+
+        bufs = []
+        buf = new_buf()
+        buf[..., :nf].copy_(f0)
+        for k in range(nb):
+            rrdb_x = buf[..., :nf]
+            for j in (1, 2, 3):
+                key = f'rrdb_trunk.{k}.rdb{j}.'
+                for i in range(1, 5):
+                    conv(f'{key}conv{i}', buf[..., :nf + (i - 1) * gc], nf + (i - 1) * gc, gc, act=LRELU,
+                         out=buf[..., nf + (i - 1) * gc: nf + i * gc])
+                nxt = new_buf()
+                # 0.2 * conv5(cat) + x  (:623) written as the next block's x
+                conv(f'{key}conv5', buf, cw, nf, out=nxt[..., :nf], res=buf[..., :nf], alpha=0.2, beta=1.0)
+                bufs.append(buf)
+                buf = nxt
+            # 0.2 * y + x  (:585), in place in the next block's x window
+            _axpby(buf[..., :nf], 0.2, rrdb_x, 1.0, buf[..., :nf])
+        z = buf[..., :nf]
+        y = conv('trunk_conv', z, nf, nf, res=f0, alpha=1.0, beta=1.0)          # (:548)
+        u1 = conv('upconv1', y, nf, nf, act=LRELU, ups=1)                        # (:549-551)
+        u2 = conv('upconv2', u1, nf, nf, act=LRELU, ups=1)                       # (:552-554)
+        hr = conv('hr_conv', u2, nf, nf, act=LRELU)
+        out = conv('conv_last', hr, nf, net.out_nc)                              # (:555)
+        if keep:
+            saved = dict(first=first, bufs=bufs, z=buf, y=y, u1=u1, u2=u2, hr=hr)
+        ctx.saved, ctx.net, ctx.names = saved, net, names
+        ctx.save_for_backward(*params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        net, names, S = ctx.net, ctx.names, ctx.saved
+        P = dict(zip(names, ctx.saved_tensors))
+        nf, gc, nb = net.nf, net.gc, net.nb
+        cw = nf + 4 * gc
+        G = {}
+
+        def spec(cin, cout, stride=1, ups=0):
+            return E.LayerSpec('c', cin, cout, 3, stride, NONE, ups)
+
+        def wgrad(key, sp, dz, xin, scale=1.0):
+            dw, db = E.conv_backward_weight(sp, dz, E.view_of(xin), P[key + '.weight'])
+            if scale != 1.0:
+                dw.mul_(scale)
+                db.mul_(scale)
+            G[key + '.weight'], G[key + '.bias'] = dw, db
+
+        def bdata(key, sp, dz, dx, **kw):
+            E.conv_backward_data(sp, dz, P[key + '.weight'], E.view_of(dx), **kw)
+            return dx
+
+        hr, u2, u1, y, zbuf = S['hr'], S['u2'], S['u1'], S['y'], S['z']
+        dz = dout.contiguous()
+        # conv_last <- hr_conv <- upconv2 <- upconv1
+        sp = spec(nf, net.out_nc)
+        wgrad('conv_last', sp, dz, hr)
+        dz = bdata('conv_last', sp, dz, torch.empty_like(hr), dsrc=hr, dact=LRELU)
+        sp = spec(nf, nf)
+        wgrad('hr_conv', sp, dz, u2)
+        dz = bdata('hr_conv', sp, dz, torch.empty_like(u2), dsrc=u2, dact=LRELU)
+        for key, src in (('upconv2', u1), ('upconv1', y)):
+            sp = spec(nf, nf, ups=1)
+            wgrad(key, sp, dz, src)
+            dup = torch.empty_like(dz)                       # grad wrt the up-sampled input
+            bdata(key, spec(nf, nf), dz, dup)
+            dsrc = torch.empty_like(src)
+            L.call('mt_sumpool', C.byref(E.view_of(dup)), C.byref(E.view_of(dsrc)), 1, L.stream_ptr())
+            dz = E.dact_(dsrc, src, LRELU) if key == 'upconv2' else dsrc
+        dy = dz                                              # grad wrt y = f0 + trunk_conv(z)
+        n, h, w, _ = dy.shape
+        sp = spec(nf, nf)
+        wgrad('trunk_conv', sp, dy, zbuf[..., :nf])
+        dcur = bdata('trunk_conv', sp, dy, torch.empty_like(dy))      # grad wrt the trunk output
+        dbuf = torch.empty((n, h, w, cw), device=dy.device, dtype=torch.float32)
+        bufs = S['bufs']
+        for k in range(nb - 1, -1, -1):
+            drr = dcur                                        # grad wrt this RRDB's output
+            d_rdb, s_rdb = drr, 0.2                           # grad wrt rdb3's output = 0.2 * drr
+            for j in (3, 2, 1):
+                key = f'rrdb_trunk.{k}.rdb{j}.'
+                buf = bufs[3 * k + (j - 1)]
+                # out = 0.2 * conv5(cat) + x  with d(out) = s_rdb * d_rdb
+                sp5 = spec(cw, nf)
+                wgrad(f'{key}conv5', sp5, d_rdb, buf, scale=0.2 * s_rdb)
+                E.conv_backward_data(sp5, d_rdb, P[f'{key}conv5.weight'], E.view_of(dbuf), dsrc=buf, dact=LRELU,
+                                     dact_c0=nf + 3 * gc, alpha=0.2 * s_rdb)
+                for i in (4, 3, 2, 1):
+                    cin = nf + (i - 1) * gc
+                    spi = spec(cin, gc)
+                    dzi = dbuf[..., cin: cin + gc]
+                    wgrad(f'{key}conv{i}', spi, dzi, buf[..., :cin])
+                    E.conv_backward_data(spi, dzi, P[f'{key}conv{i}.weight'], E.view_of(dbuf[..., :cin]), dsrc=buf,
+                                         dact=LRELU if i > 1 else NONE, dact_c0=cin - gc if i > 1 else 0,
+                                         accumulate=True)
+                # grad wrt the block input: dense part + residual path
+                d_in = torch.empty((n, h, w, nf), device=dy.device, dtype=torch.float32)
+                _axpby(dbuf[..., :nf], 1.0, d_rdb, s_rdb, d_in)
+                d_rdb, s_rdb = d_in, 1.0
+            # RRDB: out = 0.2 * y3 + x  ->  d(x) = d(rdb1 input) + drr
+            dcur = _axpby(d_rdb, 1.0, drr, 1.0, torch.empty_like(drr))
+        df0 = _axpby(dcur, 1.0, dy, 1.0, torch.empty_like(dy))
+        first = S['first']
+        dz = df0
+        strides = (1, 1, 2, 1, 2)
+        for i in range(4, -1, -1):
+            sp = spec(net.in_nc if i == 0 else nf, nf, stride=strides[i])
+            wgrad(f'conv_first.{i}', sp, dz, first[i])
+            if i > 0:
+                dz = bdata(f'conv_first.{i}', sp, dz, torch.empty_like(first[i]))
+        ctx.saved = None
+        return (None, None, None) + tuple(G[nm] for nm in names)
+
+
+class RRDBNet(nn.Module):
+    """model_chn.py:506-555."""
+
+    def __init__(self, in_nc, out_nc, nb=10, nf=64, gc=32):
+        super().__init__()
+        self.in_nc, self.out_nc, self.nb, self.nf, self.gc = in_nc, out_nc, nb, nf, gc
+        self.conv_first = nn.Sequential(
+            nn.Conv2d(in_nc, nf, (3, 3), padding=1),
+            nn.Conv2d(nf, nf, (3, 3), padding=1),
+            nn.Conv2d(nf, nf, (3, 3), stride=(2, 2), padding=1),
+            nn.Conv2d(nf, nf, (3, 3), padding=1),
+            nn.Conv2d(nf, nf, (3, 3), stride=(2, 2), padding=1))
+        rrdb_block_f = functools.partial(RRDB, nf=nf, gc=gc)
+        self.rrdb_trunk = nn.Sequential(*[rrdb_block_f() for _ in range(nb)])
+        self.trunk_conv = nn.Conv2d(nf, nf, (3, 3), (1, 1), 1, bias=True)
+        self.upconv1 = nn.Conv2d(nf, nf, (3, 3), (1, 1), 1, bias=True)
+        self.upconv2 = nn.Conv2d(nf, nf, (3, 3), (1, 1), 1, bias=True)
+        self.hr_conv = nn.Conv2d(nf, nf, (3, 3), (1, 1), 1, bias=True)
+        self.conv_last = nn.Conv2d(nf, out_nc, (3, 3), (1, 1), 1, bias=True)
+
+    def forward4(self, x4):
+        """NHWC4 in -> NHWC4 out."""
+        names, params = zip(*self.named_parameters())
+        return RRDBNetFn.apply(x4, self, names, *params)
+
+    def forward(self, x):
+        """(N,C,H,W) -> (N,out_nc,H,W), model_chn.py:538-555."""
+        return E.FromNHWC4Fn.apply(self.forward4(E.ToNHWC4Fn.apply(x)), self.out_nc)
+
+
+class RRDB(nn.Module):
+    """model_chn.py:558-585 (parameter container; arithmetic in RRDBNetFn)."""
+
+    def __init__(self, nf, gc=32):
+        super().__init__()
+        self.rdb1 = ResidualDenseBlock5C(nf, gc)
+        self.rdb2 = ResidualDenseBlock5C(nf, gc)
+        self.rdb3 = ResidualDenseBlock5C(nf, gc)
+
+
+class ResidualDenseBlock5C(nn.Module):
+    """model_chn.py:588-623 (parameter container)."""
+
+    def __init__(self, nf=64, gc=32, bias=True):
+        super().__init__()
+        self.conv1 = nn.Conv2d(nf, gc, (3, 3), (1, 1), 1, bias=bias)
+        self.conv2 = nn.Conv2d(nf + gc, gc, (3, 3), (1, 1), 1, bias=bias)
+        self.conv3 = nn.Conv2d(nf + 2 * gc, gc, (3, 3), (1, 1), 1, bias=bias)
+        self.conv4 = nn.Conv2d(nf + 3 * gc, gc, (3, 3), (1, 1), 1, bias=bias)
+        self.conv5 = nn.Conv2d(nf + 4 * gc, nf, (3, 3), (1, 1), 1, bias=bias)
+
+
+class CHN(LightningModule):
+    """model_chn.py:18-503 (training / validation path)."""
+    LOSSES_NAMES = ['loss_nh', 'loss_vh', 'loss_nvh', 'loss_perceptual', 'loss_grad']
+
+    def __init__(self, model_vgg, model_lpips, model_aligner, **kwargs):
+        super().__init__()
+        self.nn = RRDBNet(in_nc=9, out_nc=3, nb=20)
+        self.register_buffer('mean', torch.as_tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1, 1))
+        self.register_buffer('std', torch.as_tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1, 1))
+        self.model_vgg = model_vgg
+        self.model_lpips = model_lpips
+        self.model_aligner = model_aligner
+        self.kwargs = kwargs
+
+    def forward(self, x_target, v_target, x_refs_aligned, v_refs_aligned, v_maps):
+        """model_chn.py:44-85."""
+        b, c, f, h, w = x_refs_aligned.size()
+        mean, std = self.mean.reshape(3), self.std.reshape(3)
+        scale, shift = (1.0 / std).contiguous(), (-mean / std).contiguous()
+        nn_input = ops.pack_chn_input(x_target, v_target, x_refs_aligned, v_refs_aligned, v_maps, scale, shift)
+        out4 = self.nn.forward4(nn_input)                                  # (b*f,h,w,4)
+        nn_output = E.FromNHWC4Fn.apply(out4, c).reshape(b, f, c, h, w).transpose(1, 2)
+        x_target = x_target.unsqueeze(2)
+        v_target = v_target.unsqueeze(2)
+        y_hat = torch.clamp(nn_output * self.std + self.mean, 0, 1)
+        y_hat_comp = v_target * x_target + (1 - v_target) * y_hat
+        return y_hat, y_hat_comp
+
+    def _step(self, batch):
+        (x, m), y, info = batch
+        t, r_list = CHN.get_indexes(x.size(2))
+        x_ref_aligned, v_ref_aligned, v_map = self.model_aligner.align(
+            x[:, :, t], m[:, :, t], x[:, :, r_list], m[:, :, r_list])
+        y_hat, y_hat_comp = self(x[:, :, t], 1 - m[:, :, t], x_ref_aligned, v_ref_aligned, v_map)
+        return self.compute_loss(y[:, :, t], (1 - m)[:, :, t], y_hat, y_hat_comp, v_map)
+
+    def training_step(self, batch, batch_idx):
+        """model_chn.py:256-280."""
+        loss, loss_items = self._step(batch)
+        self._log_losses(loss, loss_items, 'training')
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        """model_chn.py:282-307 (PSNR/SSIM/LPIPS logging is out of scope)."""
+        loss, loss_items = self._step(batch)
+        self._log_losses(loss, loss_items, 'validation')
+        return loss
+
+    def compute_loss(self, y_target, v_target, y_hat, y_hat_comp, v_map):
+        """model_chn.py:324-376.  The reference passes 5-D tensors to the Sobel
+        conv (:371-373) and raises for more than one reference frame; here the
+        frame axis is folded into the batch (identical for one frame), as
+        :365-366 already does for the perceptual term."""
+        b, c, h, w = y_target.size()
+        f = y_hat.size(2)
+        target_img = y_target.unsqueeze(2).repeat(1, 1, f, 1, 1)
+        nh_mask = v_target.unsqueeze(2).repeat(1, 1, f, 1, 1)
+        loss_nh = LossesUtils.masked_l1(y_hat, target_img, nh_mask, reduction='sum', weight=0.50)
+        vh_mask = v_map
+        loss_vh = LossesUtils.masked_l1(y_hat, target_img, vh_mask, reduction='sum', weight=2)
+        nvh_mask = (1 - nh_mask) - vh_mask
+        loss_nvh = LossesUtils.masked_l1(y_hat_comp, target_img, nvh_mask, reduction='sum', weight=1)
+        y_hat_f = y_hat.transpose(1, 2).reshape(-1, c, h, w)
+        target_f = target_img.transpose(1, 2).reshape(-1, c, h, w)
+        loss_perceptual, *_ = LossesUtils.perceptual(y_hat_f, target_f, model_vgg=self.model_vgg, weight=0.50)
+        loss_grad = LossesUtils.grad(y_hat_f, target_f, reduction='mean', weight=1)
+        loss = loss_nh + loss_vh + loss_nvh + loss_perceptual + loss_grad
+        return loss, [loss_nh, loss_vh, loss_nvh, loss_perceptual, loss_grad]
+
+    def trainable_parameters(self):
+        """Only the RRDBNet receives gradients (aligner, VGG, LPIPS are frozen
+        in effect: their .grad stays None in the reference)."""
+        return list(self.nn.parameters())
+
+    def configure_optimizers(self):
+        """model_chn.py:378-391."""
+        optimizer = FlatAdam(self.trainable_parameters(), lr=self.kwargs['lr'])
+        lr_scheduler = torch.optim.lr_scheduler.StepLR(
+            optimizer, step_size=self.kwargs['lr_scheduler_step_size'], gamma=self.kwargs['lr_scheduler_gamma'])
+        return {'optimizer': optimizer, 'lr_scheduler': lr_scheduler}
+
+    def _log_losses(self, loss, loss_items, split):
+        """model_chn.py:393-406."""
+        self.log('loss_{}'.format(split), loss)
+        for i, loss_item_id in enumerate(CHN.LOSSES_NAMES):
+            self.log('loss_{}_{}'.format(loss_item_id, split), loss_items[i])
+
+    @staticmethod
+    def get_indexes(size):
+        """model_chn.py:442-457."""
+        t, r_list = size // 2, list(range(size))
+        r_list.pop(t)
+        return t, r_list

@@ -1,0 +1,82 @@
+"""Adam over ONE flat fp32 buffer (torch.optim.Adam semantics with default
+betas/eps, model_dfpn.py:302 / model_chn.py:385) as a single fused HIP kernel,
+plus the flat gradient buffer the data-parallel all-reduce works on."""
+import math
+
+import torch
+
+from . import _lib as L
+from . import engine as E
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        params = [p for p in params if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._plist = params
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.flat_p = torch.empty((n,), device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros((n,), device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.step_count = 0
+        self.grad_scale = 1.0          # 1/world_size after a SUM all-reduce
+        off = 0
+        self._slices = []
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.flat_p[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat_p[off:off + k].view(p.shape)
+                p.grad = self.flat_g[off:off + k].view(p.shape)
+                self._slices.append((off, k))
+                off += k
+        E.bump_weight_epoch()
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients stay views of the flat buffer (autograd accumulates in
+        place), so they are zeroed, never dropped."""
+        self.flat_g.zero_()
+        for p, (off, k) in zip(self._plist, self._slices):
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                p.grad = self.flat_g[off:off + k].view(p.shape)
+
+    def _gather_foreign_grads(self):
+        for p, (off, k) in zip(self._plist, self._slices):
+            want = self.flat_g.data_ptr() + 4 * off
+            if p.grad is None:
+                self.flat_g[off:off + k].zero_()
+                p.grad = self.flat_g[off:off + k].view(p.shape)
+            elif p.grad.data_ptr() != want:
+                self.flat_g[off:off + k].copy_(p.grad.reshape(-1))
+                p.grad = self.flat_g[off:off + k].view(p.shape)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._gather_foreign_grads()
+        g = self.param_groups[0]
+        b1, b2 = g['betas']
+        self.step_count += 1
+        bc1 = 1.0 - b1 ** self.step_count
+        bc2 = 1.0 - b2 ** self.step_count
+        L.call('mt_adam_step', L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+               self.flat_p.numel(), b1, b2, g['lr'] / bc1, 1.0 / math.sqrt(bc2), g['eps'], self.grad_scale,
+               L.stream_ptr())
+        E.bump_weight_epoch()
+        return loss
+
+    def state_dict(self):
+        return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
+                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.step_count = sd['step']
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        for g, s in zip(self.param_groups, sd['param_groups']):
+            g.update(s)

@@ -122,8 +122,8 @@ def masked_l1(y_hat, y, mask, batch_mask=None, reduction='mean', weight=1):
 
 def sobel_grads(x):
     """Depth-wise Sobel H and V responses, utils.py:131-136, 211-214."""
-    gh = torch.tensor([[1., 0., -1.], [2., 0., -2.], [1., 0., -1.]])
-    gv = torch.tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]])
+    gh = torch.tensor([[1., 0., -1.], [2., 0., -2.], [1., 0., -1.]], dtype=x.dtype)
+    gv = torch.tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]], dtype=x.dtype)
     c = x.shape[1]
     wh = gh.view(1, 1, 3, 3).repeat(c, 1, 1, 1)
     wv = gv.view(1, 1, 3, 3).repeat(c, 1, 1, 1)

@@ -1,0 +1,294 @@
+"""Kernel-level parity of the C-ABI entry points (through ctypes) against the
+CPU oracle / plain torch fp32 on the same seeded inputs.  GPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import seeded as S
+from oracle import ref_torch as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3   # north_star: 1e-3 relative fp32
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def assert_close(a, b, tol=RTOL, what=''):
+    e = rel_err(a, b)
+    assert e <= tol, f'{what}: max-normalised error {e:.3e} > {tol}'
+
+
+@pytest.fixture(scope='module')
+def mt():
+    import master_thesis_amd as mt
+    from master_thesis_amd import _lib
+    _lib.load()
+    return mt
+
+
+CONV_CASES = [
+    # (N, H, W, cin, cout, k, stride, kind, act)
+    (2, 16, 16, 1, 128, 3, 1, 'c', 1),
+    (3, 16, 16, 128, 256, 3, 1, 'c', 1),
+    (2, 20, 28, 10, 128, 5, 1, 'c', 1),
+    (2, 33, 21, 128, 128, 5, 2, 'c', 1),
+    (2, 32, 32, 128, 128, 3, 2, 'c', 0),
+    (2, 8, 12, 128, 128, 3, 2, 't', 1),
+    (2, 8, 8, 128, 128, 5, 2, 't', 1),
+    (1, 16, 16, 128, 2, 3, 1, 'c', 0),
+    (2, 16, 16, 256, 16, 3, 1, 'c', 1),
+    (2, 16, 16, 4, 2, 5, 1, 'c', 0),
+    (2, 24, 24, 96, 32, 3, 1, 'c', 2),
+    (1, 40, 24, 64, 64, 3, 1, 'c', 2),
+    (1, 16, 16, 160, 32, 3, 1, 'c', 2),
+    (2, 16, 16, 3, 64, 3, 1, 'c', 1),
+]
+
+
+def _torch_layer(x, w, b, k, stride, kind, act):
+    if kind == 'c':
+        y = F.conv2d(x, w, b, stride=stride, padding=k // 2)
+    else:
+        y = F.conv_transpose2d(x, w, b, stride=stride, padding=k // 2, output_padding=1)
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = F.leaky_relu(y, 0.2)
+    return y
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_forward_backward(mt, case):
+    """mt_conv_run (fwd + bwd-data), mt_wgrad_run/reduce, mt_bias_grad vs torch
+    fp32 conv2d / conv_transpose2d and its autograd, plus the naive kernel."""
+    from master_thesis_amd import engine as E
+    n, h, w, cin, cout, k, stride, kind, act = case
+    tag = 'conv.' + '.'.join(map(str, case))
+    x = S.uniform(tag + '.x', (n, cin, h, w), -1, 1)
+    wshape = (cout, cin, k, k) if kind == 'c' else (cin, cout, k, k)
+    wt = S.uniform(tag + '.w', wshape, -0.2, 0.2)
+    bs = S.uniform(tag + '.b', (cout,), -0.5, 0.5)
+    xr, wr, br = x.clone().requires_grad_(True), wt.clone().requires_grad_(True), bs.clone().requires_grad_(True)
+    yr = _torch_layer(xr, wr, br, k, stride, kind, act)
+    gy = S.uniform(tag + '.gy', tuple(yr.shape), -1, 1)
+    if act:
+        # a pre-activation within rounding of 0 may land on either side of the
+        # ReLU kink on the two devices: keep such elements out of the gradient
+        pre = _torch_layer(x, wt, bs, k, stride, kind, 0)
+        gy = gy * (pre.abs() > 1e-4).float()
+    yr.backward(gy)
+
+    spec = E.LayerSpec(kind, cin, cout, k, stride, act)
+    xg = x.to(dev()).requires_grad_(True)
+    wg, bg = wt.to(dev()).requires_grad_(True), bs.to(dev()).requires_grad_(True)
+    x4 = E.ToNHWC4Fn.apply(xg)
+    y4 = E.conv_stack(x4, [spec], [wg, bg])
+    y = E.FromNHWC4Fn.apply(y4, cout)
+    assert_close(y, yr, what='forward')
+    if y4.shape[3] > cout:
+        assert float(y4.detach()[..., cout:].abs().max()) == 0.0, 'channel padding must stay zero'
+    y.backward(gy.to(dev()))
+    assert_close(xg.grad, xr.grad, what='bwd-data')
+    assert_close(wg.grad, wr.grad, what='wgrad')
+    assert_close(bg.grad, br.grad, what='bias grad')
+
+    # naive restatement kernel agrees with the MFMA kernel
+    from master_thesis_amd import _lib as L
+    d = L.Conv()
+    out2 = torch.empty_like(y4)
+    d.x, d.y = E.view_of(x4.detach()), E.view_of(out2)
+    d.wt = E._pack(wg.detach(), 0 if kind == 'c' else 1, 'f').data_ptr()
+    d.bias = E._pad_bias(bg.detach(), cout).data_ptr()
+    d.KH = d.KW = k
+    d.stride, d.pad, d.transposed, d.act, d.alpha = stride, k // 2, 0 if kind == 'c' else 1, act, 1.0
+    d.res, d.dsrc = E.null_view(), E.null_view()
+    L.call('mt_conv_run_naive', C.byref(d), L.stream_ptr())
+    assert_close(out2, y4, tol=1e-5, what='naive vs mfma')
+
+
+def test_conv_stack_chain(mt):
+    """A 3-layer chain with fused ReLU gating in the backward."""
+    from master_thesis_amd import engine as E
+    from master_thesis_amd import _lib as L
+    specs = [E.LayerSpec('c', 12, 64, 5, 1, L.ACT_RELU), E.LayerSpec('c', 64, 64, 3, 2, L.ACT_RELU),
+             E.LayerSpec('t', 64, 8, 3, 2, L.ACT_NONE)]
+    shapes = [(64, 12, 5, 5), (64,), (64, 64, 3, 3), (64,), (64, 8, 3, 3), (8,)]
+    ps = [S.uniform(f'chain.p{i}', s, -0.15, 0.15) for i, s in enumerate(shapes)]
+    x = S.uniform('chain.x', (2, 12, 24, 24), -1, 1)
+    pr = [p.clone().requires_grad_(True) for p in ps]
+    xr = x.clone().requires_grad_(True)
+    y = F.relu(F.conv2d(xr, pr[0], pr[1], padding=2))
+    y = F.relu(F.conv2d(y, pr[2], pr[3], stride=2, padding=1))
+    y = F.conv_transpose2d(y, pr[4], pr[5], stride=2, padding=1, output_padding=1)
+    gy = S.uniform('chain.gy', tuple(y.shape), -1, 1)
+    y.backward(gy)
+    pg = [p.to(dev()).requires_grad_(True) for p in ps]
+    xg = x.to(dev()).requires_grad_(True)
+    out = E.FromNHWC4Fn.apply(E.conv_stack(E.ToNHWC4Fn.apply(xg), specs, pg), 8)
+    assert_close(out, y, what='chain fwd')
+    out.backward(gy.to(dev()))
+    assert_close(xg.grad, xr.grad, what='chain dx')
+    for i, (a, b) in enumerate(zip(pg, pr)):
+        assert_close(a.grad, b.grad, what=f'chain grad {i}')
+
+
+def test_correlation(mt, golden):
+    g = golden('g1_corr')
+    M = mt.model_dfpn.CorrelationVGG
+    for tag, (b, r, c) in {'small': (2, 2, 64), 'c512': (1, 1, 512)}.items():
+        ft = S.uniform(f'g1.ft.{tag}', (b, c, 16, 16), -1, 2).to(dev())
+        fr = S.uniform(f'g1.fr.{tag}', (b, c, r, 16, 16), -1, 2).to(dev())
+        vt = (S.uniform(f'g1.vt.{tag}', (b, 1, 16, 16)) > 0.3).float().to(dev())
+        vr = (S.uniform(f'g1.vr.{tag}', (b, 1, r, 16, 16)) > 0.3).float().to(dev())
+        assert_close(M.correlation_masked_4d(ft, vt, fr, vr), torch.from_numpy(g[f'{tag}.masked']), what=tag)
+        assert_close(M.correlation_masked_4d(ft, None, fr, None), torch.from_numpy(g[f'{tag}.unmasked']), what=tag)
+
+
+def _np_warp_indices(grid, h, w):
+    """numpy restatement of grid_sample's index arithmetic (align_corners=True):
+    ix = ((g+1)/2)*(W-1); corner = floor; nearest = rint (ties to even)."""
+    g = grid.numpy().astype(np.float32)
+    ix = ((g[..., 0] + np.float32(1)) / np.float32(2)) * np.float32(w - 1)
+    iy = ((g[..., 1] + np.float32(1)) / np.float32(2)) * np.float32(h - 1)
+    x0, y0 = np.floor(ix).astype(np.int64), np.floor(iy).astype(np.int64)
+    nx, ny = np.rint(ix).astype(np.int64), np.rint(iy).astype(np.int64)
+    inside = (nx >= 0) & (nx < w) & (ny >= 0) & (ny < h)
+    nx, ny = np.where(inside, nx, -1), np.where(inside, ny, -1)
+    return np.stack([y0, x0, ny, nx], axis=-1)
+
+
+def test_warp(mt, golden):
+    from make_inputs import warp_grid
+    from master_thesis_amd import ops
+    g = golden('g2_warp')
+    for s in (16, 64):
+        x = S.uniform(f'g2.x.{s}', (2, 3, 2, s, s))
+        v = (S.uniform(f'g2.v.{s}', (2, 1, 2, s, s)) > 0.4).float()
+        grid = warp_grid(2, 2, s, s, f'g2.g.{s}')
+        gg = grid.to(dev()).requires_grad_(True)
+        xa, va, idx = ops.align_set(x.to(dev()), v.to(dev()), gg, want_idx=True)
+        assert_close(xa, torch.from_numpy(g[f'x.{s}']), tol=1e-5, what='warp x')
+        # bit-exact against the oracle on THIS machine's inputs (the seeded grids
+        # go through cos/sin/affine_grid, which may differ by 1 ulp between hosts)
+        xo, vo = O.align_set(x, v, grid)
+        assert np.array_equal(va.cpu().numpy(), vo.numpy()), 'nearest-warped visibility must be bit-exact'
+        assert (va.cpu().numpy() != g[f'v.{s}']).mean() < 1e-3
+        assert np.array_equal(idx.cpu().numpy().astype(np.int64), _np_warp_indices(grid, s, s)), 'warp indices'
+        wgt = S.uniform(f'g2.w.{s}', (2, 3, 2, s, s), -1, 1).to(dev())
+        (xa * wgt).sum().backward()
+        assert_close(gg.grad, torch.from_numpy(g[f'dgrid.{s}']), tol=1e-4, what='warp dgrid')
+
+
+def test_warp_nonsquare_and_cpn(mt, golden):
+    g = golden('g11_cpn_warp')
+    b, r, h, w = 1, 3, 32, 48
+    x = S.uniform('g11.x', (b, 3, r, h, w)).to(dev())
+    m = (S.uniform('g11.m', (b, 1, r, h, w)) > 0.6).float().to(dev())
+    m_t = (S.uniform('g11.mt', (b, 1, h, w)) > 0.6).float().to(dev())
+    xa, va, vm = mt.CPN.warp(x, m, m_t, torch.from_numpy(g['theta']).to(dev()))
+    assert_close(xa, torch.from_numpy(g['x_aligned']), tol=1e-4, what='cpn x')
+    assert (va.cpu().numpy() != g['v_aligned']).mean() < 2e-3
+    assert (vm.cpu().numpy() != g['v_maps']).mean() < 2e-3
+
+
+def test_resize(mt, golden):
+    g = golden('g3_resize')
+    FU, TU = mt.FlowsUtils, mt.TransformsUtils
+    fl = S.affine_flow(2, 2, 16, 16, 0, 'g3.f16').to(dev())
+    assert_close(FU.resize_flow(fl, (64, 64), 'bilinear'), torch.from_numpy(g['flow.16to64.bilinear']), 1e-5)
+    fl64 = S.affine_flow(1, 2, 64, 64, 0, 'g3.f64').to(dev())
+    assert_close(FU.resize_flow(fl64, (256, 256), 'bilinear')[:, :, ::5, ::7],
+                 torch.from_numpy(g['flow.64to256.bilinear']), 1e-5)
+    assert np.array_equal(FU.resize_flow(fl64, (16, 16)).cpu().numpy(), O.resize_flow(fl64.cpu(), (16, 16)).numpy())
+    assert_close(FU.resize_flow(fl64, (16, 16)), torch.from_numpy(g['flow.64to16.nearest']), 1e-6)
+    fl48 = S.affine_flow(1, 1, 48, 80, 0, 'g3.f48').to(dev())
+    assert_close(FU.resize_flow(fl48, (40, 56), 'bilinear'), torch.from_numpy(g['flow.48x80to40x56.bilinear']), 1e-5)
+    assert np.array_equal(FU.resize_flow(fl48, (16, 16)).cpu().numpy(), O.resize_flow(fl48.cpu(), (16, 16)).numpy())
+    assert_close(FU.resize_flow(fl48, (16, 16)), torch.from_numpy(g['flow.48x80to16.nearest']), 1e-6)
+    x = S.uniform('g3.x', (2, 3, 2, 64, 64)).to(dev())
+    v = (S.uniform('g3.v', (2, 1, 2, 64, 64)) > 0.4).float().to(dev())
+    y = S.uniform('g3.y', (2, 3, 2, 64, 64)).to(dev())
+    xn, vn, yn = TU.resize_set(x, v, y, 16)
+    assert_close(xn, torch.from_numpy(g['set16.x']), 1e-5)
+    assert_close(yn, torch.from_numpy(g['set16.y']), 1e-5)
+    assert np.array_equal(vn.cpu().numpy(), g['set16.v'])
+    a, b, c, d = TU.resize_set_bis(x[:, :, 0], v[:, :, 0], x, v, (32, 32))
+    assert_close(a, torch.from_numpy(g['bis32.xt']), 1e-5)
+    assert_close(c, torch.from_numpy(g['bis32.xr']), 1e-5)
+    assert np.array_equal(b.cpu().numpy(), g['bis32.mt']) and np.array_equal(d.cpu().numpy(), g['bis32.mr'])
+    x96 = S.uniform('g3.x96', (1, 3, 1, 96, 72)).to(dev())
+    v96 = (S.uniform('g3.v96', (1, 1, 1, 96, 72)) > 0.4).float().to(dev())
+    a, b, _, _ = TU.resize_set_bis(x96[:, :, 0], v96[:, :, 0], x96, v96, (64, 64))
+    assert_close(a, torch.from_numpy(g['bis64.xt']), 1e-5)
+    assert np.array_equal(b.cpu().numpy(), g['bis64.mt'])
+
+
+def test_resize_bilinear_backward(mt):
+    fl = S.affine_flow(2, 3, 16, 16, 0, 'rb.f')
+    fr = fl.clone().requires_grad_(True)
+    out = O.resize_flow(fr, (64, 64), 'bilinear')
+    gy = S.uniform('rb.gy', tuple(out.shape), -1, 1)
+    out.backward(gy)
+    fg = fl.to(dev()).requires_grad_(True)
+    mt.FlowsUtils.resize_flow(fg, (64, 64), 'bilinear').backward(gy.to(dev()))
+    assert_close(fg.grad, fr.grad, 1e-5, 'bilinear bwd')
+
+
+def test_losses(mt):
+    LU = mt.LossesUtils
+    b, c, r, h = 3, 3, 2, 24
+    a = S.uniform('l.a', (b, c, r, h, h), -1, 1)
+    t = S.uniform('l.t', (b, c, r, h, h), -1, 1)
+    m = (S.uniform('l.m', (b, 1, r, h, h)) > 0.5).float()
+    for use in ([True, False, True], [False, False, False], None):
+        for red in ('mean', 'sum'):
+            ar = a.clone().requires_grad_(True)
+            ref = O.masked_l1(ar, t, m, use, red, 0.7)
+            ag = a.to(dev()).requires_grad_(True)
+            use_t = torch.tensor(use) if use is not None else None
+            out = LU.masked_l1(ag, t.to(dev()), m.to(dev()), use_t.to(dev()) if use_t is not None else None, red, 0.7)
+            assert abs(float(out) - float(ref.sum())) <= 1e-5 * max(1.0, abs(float(ref.sum()))), (use, red)
+            if ref.requires_grad:
+                ref.sum().backward()
+                out.backward()
+                assert_close(ag.grad, ar.grad, 1e-5, f'masked_l1 grad {use} {red}')
+    y1 = S.uniform('l.y1', (4, 3, 20, 28))
+    y2 = S.uniform('l.y2', (4, 3, 20, 28))
+    yr = y1.clone().requires_grad_(True)
+    ref = O.grad_loss(yr, y2, 1.0)
+    ref.backward()
+    yg = y1.to(dev()).requires_grad_(True)
+    out = LU.grad(yg, y2.to(dev()), 'mean', 1.0)
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 1e-5 * abs(float(ref))
+    assert_close(yg.grad, yr.grad, 1e-5, 'sobel grad')
+
+
+def test_adam_matches_torch(mt):
+    ps = [S.uniform(f'adam.p{i}', s, -1, 1) for i, s in enumerate([(7, 3, 3, 3), (7,), (130, 5)])]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt_r = torch.optim.Adam(ref, lr=1e-2)
+    mine = [torch.nn.Parameter(p.to(dev())) for p in ps]
+    opt = mt.FlatAdam(mine, lr=1e-2)
+    for step in range(3):
+        opt.zero_grad()
+        opt_r.zero_grad()
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            g = S.uniform(f'adam.g{step}.{i}', tuple(b.shape), -1, 1)
+            b.grad = g.clone()
+            a.grad.add_(g.to(dev()))
+        opt.step()
+        opt_r.step()
+    for a, b in zip(mine, ref):
+        assert_close(a, b, 1e-5, 'adam')
