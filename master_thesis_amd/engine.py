@@ -14,6 +14,31 @@ from . import _lib as L
 
 WEIGHT_EPOCH = 0          # bumped by the optimizer: packed-weight cache key
 _pack_cache = {}
+PROFILE = None            # list -> every conv-engine launch appends (kernel, flops, ev0, ev1)
+
+
+def _igemm_name(co):
+    return 'igemm_kernel<2,2,2,2>' if co > 64 else ('igemm_kernel<2,2,2,1>' if co > 32 else 'igemm_kernel<4,1,1,1>')
+
+
+class _Prof:
+    """HIP events around ONE launch on the current stream (bench.py roofline)."""
+
+    def __init__(self, name, flops):
+        self.on = PROFILE is not None
+        if self.on:
+            self.name, self.flops = name, flops
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def __enter__(self):
+        if self.on:
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e1.record()
+            PROFILE.append((self.name, self.flops, self.e0, self.e1))
 
 
 def bump_weight_epoch():
@@ -124,7 +149,12 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
     d.res = view_of(res) if res is not None else null_view()
     d.beta = beta
     d.dsrc = null_view()
-    L.call('mt_conv_run', C.byref(d), L.stream_ptr())
+    if spec.kind == 'c':
+        flops = 2.0 * n * ho * wo * spec.cin * spec.cout * spec.k * spec.k
+    else:
+        flops = 2.0 * n * h * w_ * spec.cin * spec.cout * spec.k * spec.k
+    with _Prof(_igemm_name(d.y.C), flops):
+        L.call('mt_conv_run', C.byref(d), L.stream_ptr())
     return out
 
 
@@ -144,7 +174,10 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     d.dsrc = view_of(dsrc) if dsrc is not None else null_view()
     d.dact, d.dact_c0 = dact, dact_c0
     d.accumulate = 1 if accumulate else 0
-    L.call('mt_conv_run', C.byref(d), L.stream_ptr())
+    side = d.x if spec.kind == 'c' else yv          # the conv's output side
+    flops = 2.0 * side.N * side.H * side.W * spec.cin * spec.cout * spec.k * spec.k
+    with _Prof(_igemm_name(yv.C), flops):
+        L.call('mt_conv_run', C.byref(d), L.stream_ptr())
 
 
 def _splits(blocks_base, pixels):
@@ -179,7 +212,16 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True):
     d.splits = _splits(tiles * t, pixels)
     slabs = torch.empty((d.splits * ap * t * bp,), device=w.device, dtype=torch.float32)
     d.slabs = slabs.data_ptr()
-    L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
+    if ap > 64 and bp > 64:
+        kname = 'wgrad_kernel<2,2,2,2>'
+    elif ap <= 32:
+        kname = 'wgrad_kernel<1,4,1,1>'
+    elif bp <= 32:
+        kname = 'wgrad_kernel<4,1,1,1>'
+    else:
+        kname = 'wgrad_kernel<2,2,1,1>'
+    with _Prof(kname, 2.0 * pixels * spec.cin * spec.cout * t):
+        L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
     dw = torch.empty_like(w)
     # both Conv2d (O,I,k,k) and ConvTranspose2d (I,O,k,k): a = dim 0, b = dim 1
     L.call('mt_wgrad_reduce', L.ptr(slabs), d.splits, ap, t, bp, L.ptr(dw), a, b, b * t, t, 1, 0, L.stream_ptr())
