@@ -109,27 +109,44 @@ def corr_roofline(b_pairs=2048):
             'tflops': flops / (ms * 1e-3) / 1e12}
 
 
+def host_cores():
+    """CPU cores this process may really use: affinity mask and cgroup quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(frames, size, budget_s):
     """The CPU oracle (port of the reference path) timed on this box's host
-    cores on a bounded sample: ONE clip of the batch, one DFPN training step
-    (forward + loss + backward), fp32."""
+    cores on a bounded sample: TWO clips of the 8-clip batch, one DFPN training
+    step (forward + loss + backward), fp32, all cores of the cgroup share."""
     sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
     import seeded as S
     from oracle import ref_torch as O
-    cores = os.cpu_count()
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = S.seeded_state_dict(S.dfpn_shapes())
     S.add_buffers(sd)
     names = [k for k in sd if 'model_vgg' not in k and k not in ('mean', 'std')]
     for n in names:
         sd[n] = sd[n].clone().requires_grad_(True)
-    batch = S.synthetic_batch(1, frames, size, size, seed=1, flows_use=[True])
+    clips = 2
+    batch = S.synthetic_batch(clips, frames, size, size, seed=1)
     t0 = time.perf_counter()
     loss, _ = O.dfpn_training_step(sd, batch)
     torch.autograd.grad(loss, [sd[n] for n in names])
     dt = time.perf_counter() - t0
-    return {'value': frames / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': f'1 clip x {frames} frames x {size}x{size}, one DFPN training step (fwd+loss+bwd) on the '
+    return {'value': clips * frames / dt, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{clips} clips x {frames} frames x {size}x{size}, one DFPN training step (fwd+loss+bwd) on the '
                       f'oracle (oracle/ref_torch.py, torch fp32 CPU ops), {dt:.1f} s'}
 
 

@@ -34,6 +34,18 @@ enum mt_status {
 };
 
 enum mt_act { MT_ACT_NONE = 0, MT_ACT_RELU = 1, MT_ACT_LRELU02 = 2 };
+/* Arithmetic of the MFMA contraction (inputs and outputs are fp32 either way):
+ * MT_PREC_F32    v_mfma_f32_32x32x2_f32, exact fp32 products (157 TFLOP/s peak);
+ * MT_PREC_BF16X3 every fp32 operand split into 2 bf16 terms, 3 partial products
+ *                on v_mfma_f32_32x32x16_bf16, fp32 accumulate: 17-18 significant
+ *                bits (~4e-6 relative per layer), 5.3x the fp32-MFMA rate;
+ * MT_PREC_BF16X6 3 bf16 terms, 6 partial products: >= 24 significant bits =
+ *                fp32-equivalent, 2.7x the fp32-MFMA rate. */
+enum mt_precision { MT_PREC_F32 = 0, MT_PREC_BF16X3 = 1, MT_PREC_BF16X6 = 2 };
+/* Kernel selection of mt_conv_run: AUTO picks the LDS halo-tile direct
+ * convolution for stride-1 3x3/5x5 "same" layers (split precisions, X.C % 8 ==
+ * 0) and the implicit-GEMM gather kernel otherwise; IGEMM forces the latter. */
+enum mt_algo { MT_ALGO_AUTO = 0, MT_ALGO_IGEMM = 1 };
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -88,6 +100,8 @@ typedef struct {
   mt_view dsrc;       /* dsrc.p == NULL: none */
   int32_t dact, dact_c0;
   int32_t accumulate;
+  int32_t precision;  /* mt_precision; split precisions need wt from mt_weight_pack_split */
+  int32_t algo;       /* mt_algo */
 } mt_conv;
 
 int mt_conv_run(const mt_conv* d, void* stream);
@@ -107,6 +121,7 @@ typedef struct {
   int32_t KH, KW, stride, pad, ups;
   int32_t splits;
   float* slabs;
+  int32_t precision;  /* mt_precision */
 } mt_wgrad;
 
 int mt_wgrad_run(const mt_wgrad* d, void* stream);
@@ -126,6 +141,15 @@ int mt_bias_grad(const mt_view* d, float* db, int32_t C, float* ws,
 int mt_weight_pack(const float* src, int32_t A, int32_t B, int32_t T,
                    int64_t sa, int64_t sb, int64_t st, float* dst, int32_t AP,
                    int32_t BP, void* stream);
+/* same selection, split into bf16 planes for the split precisions:
+ * dst = [NS][AP][Kp] bf16 (plane s = s-th term; NS = 2 for BF16X3, 3 for
+ * BF16X6), Kp = T*BP rounded up to a multiple of 32.  flip = 1 reverses the
+ * tap order (t -> T-1-t): with a and b swapped this turns the backward-data of
+ * a stride-1 "same" convolution into a plain forward convolution. */
+int mt_weight_pack_split(const float* src, int32_t A, int32_t B, int32_t T,
+                         int64_t sa, int64_t sb, int64_t st, void* dst,
+                         int32_t AP, int32_t BP, int32_t precision, int32_t flip,
+                         void* stream);
 int mt_pad_vector(const float* src, int32_t n, float* dst, int32_t np, void* stream);
 
 /* ---- layout / streaming kernels --------------------------------------- */

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmt355.so')
-SOURCES = [('conv.hip', []), ('stream.hip', ['-ffp-contract=off']), ('api.cpp', [])]
+SOURCES = [('conv.hip', []), ('conv_halo.hip', []), ('stream.hip', ['-ffp-contract=off']), ('api.cpp', [])]
 
 
 def _stale(target, deps):
@@ -19,7 +19,8 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(ROOT, 'include', 'mt355.h')]
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'),
+               os.path.join(ROOT, 'include', 'mt355.h')]
     objs = []
     for src, extra in SOURCES:
         path = os.path.join(CSRC, src)

@@ -15,25 +15,9 @@
 // four consumes the k-pair {8q+j, 8q+4+j}); LDS rows are padded to 36 floats,
 // which keeps the b128 reads conflict-free.
 #include "common.h"
+#include "conv_common.h"
 
 namespace {
-
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;
-
-struct ConvK {
-  const float* x; long xsn, xsh, xsw; int H, W, C;   // physical dims of the gathered tensor
-  int xni; long xsg; int yni; long ysg;              // two-level image index of x and y
-  const float* wt; const float* bias;
-  float* y; long ysn, ysh, ysw; int Ho, Wo, Co;
-  int N, KH, KW, stride, pad, transposed, ups;
-  int M, K;
-  int act; float alpha;
-  const float* res; long rsn, rsh, rsw; float beta;
-  const float* ds; long dsn, dsh, dsw; int dact, dact_c0;
-  int accumulate;
-  int zb, zdiv; long xz, wz, yz;   // batched GEMM over blockIdx.z (correlation)
-};
 
 template <int WGM, int WGN, int TM, int TN>
 __global__ __launch_bounds__(256) void igemm_kernel(ConvK p) {
@@ -46,7 +30,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvK p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int li = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
   if (p.zb > 1) {
     const int z = blockIdx.z;
     p.x += (long)(z / p.zdiv) * p.xz;
@@ -156,35 +140,154 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvK p) {
     __syncthreads();
   }
 
-  // ---- epilogue -----------------------------------------------------------
-  // C/D layout of the 32x32 tile: col (o) = lane & 31, row (pixel) =
-  // (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+  igemm_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, li, lh);
+}
+
+// ================================================================== split ==
+// Split-bf16 variants.  Every fp32 operand is written as a sum of NS bf16
+// terms, a = a_0 + a_1 (+ a_2), a_0 = bf16(a), a_1 = bf16(a - a_0), ... and the
+// fp32 product is accumulated from the bf16 x bf16 partial products (each exact
+// in fp32) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+//   NS = 2 ("bf16x3"): a0b0 + a0b1 + a1b0          17-18 significant bits,
+//                      ~4e-6 relative per layer, 16/3 = 5.3x the fp32-MFMA rate
+//   NS = 3 ("bf16x6"): all i + j <= 2 (6 products)  >= 24 significant bits =
+//                      fp32-equivalent, 16/6 = 2.7x the fp32-MFMA rate
+// Weights are split once at pack time; activations are split while they are
+// staged into LDS.  K per LDS stage: BKT = 32 (NS = 2) or 16 (NS = 3) so that
+// both fit two blocks per CU.
+template <int WGM, int WGN, int TM, int TN, int NS>
+__global__ __launch_bounds__(256) void igemm_split_kernel(ConvK p) {
+  constexpr int BKT = NS == 3 ? 16 : 32;            // k per LDS stage
+  constexpr int LD = BKT + 8;                       // bf16 per LDS row (+16 B pad: conflict-free b128 reads)
+  constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+  constexpr int FPR = BKT / 4, RPP = 256 / FPR;     // float4 per A row, A rows per pass
+  constexpr int RA = BM / RPP;
+  constexpr int CPR = BKT / 8;                      // 16-B chunks per B row
+  constexpr int NCH = NS * BN * CPR, RB = (NCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) __bf16 sA[2][NS][BM * LD];
+  __shared__ __attribute__((aligned(16))) __bf16 sB[2][NS][BN * LD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
+
+  const int col4 = tid % FPR, row0 = tid / FPR;
+  long a_off[RA];
+  int a_oy[RA], a_ox[RA];
+  bool a_ok[RA];
+  const int HWo = p.Ho * p.Wo;
 #pragma unroll
-  for (int a = 0; a < TM; ++a) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= p.M) continue;
-      const int n = m / HWo;
-      const int rem = m - n * HWo;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      const long yo = (long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + (long)oy * p.ysh + (long)ox * p.ysw;
-      const long ro = p.res ? (long)n * p.rsn + (long)oy * p.rsh + (long)ox * p.rsw : 0;
-      const long so = p.ds ? (long)n * p.dsn + (long)oy * p.dsh + (long)ox * p.dsw : 0;
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int o = n0 + wn * TN * 32 + b * 32 + li;
-        if (o >= p.Co) continue;
-        float v = acc[a][b][r];
-        if (p.bias) v += p.bias[o];
-        v = mt_act_fn(v, p.act) * p.alpha;
-        if (p.res) v += p.beta * p.res[ro + o];
-        if (p.accumulate) v += p.y[yo + o];
-        if (p.ds && o >= p.dact_c0) v *= mt_dact_fn(p.ds[so + o], p.dact);
-        p.y[yo + o] = v;
-      }
-    }
+  for (int i = 0; i < RA; ++i) {
+    int m = m0 + row0 + RPP * i;
+    a_ok[i] = m < p.M;
+    int mm = a_ok[i] ? m : 0;
+    int n = mm / HWo;
+    int r = mm - n * HWo;
+    a_oy[i] = r / p.Wo;
+    a_ox[i] = r - a_oy[i] * p.Wo;
+    a_off[i] = (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
   }
+  int kc = col4 * 4, kkh = 0, kkw = 0;
+  while (kc >= p.C) { kc -= p.C; if (++kkw == p.KW) { kkw = 0; ++kkh; } }
+  const int HL = p.H << p.ups, WL = p.W << p.ups;
+  const int smask = p.stride - 1, sshift = p.stride >> 1;
+  const __bf16* wt16 = reinterpret_cast<const __bf16*>(p.wt);
+  const long plane = (long)p.Co * p.Kp;
+
+  f32x4 ra[RA];
+  bf16x8 rb[RB];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      bool ok = a_ok[i] && kkh < p.KH;
+      int iy, ix;
+      if (!p.transposed) {
+        iy = a_oy[i] * p.stride - p.pad + kkh;
+        ix = a_ox[i] * p.stride - p.pad + kkw;
+        ok = ok && (unsigned)iy < (unsigned)HL && (unsigned)ix < (unsigned)WL;
+      } else {
+        int ty = a_oy[i] + p.pad - kkh, tx = a_ox[i] + p.pad - kkw;
+        ok = ok && ty >= 0 && tx >= 0 && ((ty | tx) & smask) == 0;
+        iy = ty >> sshift; ix = tx >> sshift;
+        ok = ok && iy < HL && ix < WL;
+      }
+      iy >>= p.ups; ix >>= p.ups;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(p.x + a_off[i] + (long)iy * p.xsh + (long)ix * p.xsw + kc);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int c = tid + 256 * i;               // chunk id over [plane][BN rows][CPR x 16 B]
+      const int pl = c / (BN * CPR), w = c % (BN * CPR), row = w / CPR, ch = w % CPR;
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+      if (c < NCH && n0 + row < p.Co)
+        v = *reinterpret_cast<const bf16x8*>(wt16 + pl * plane + (long)(n0 + row) * p.Kp + kt * BKT + ch * 8);
+      rb[i] = v;
+    }
+    kc += BKT;
+    while (kc >= p.C) { kc -= p.C; if (++kkw == p.KW) { kkw = 0; ++kkh; } }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      bf16x4 parts[NS];
+      split4<NS>(ra[i], parts);
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+        *reinterpret_cast<bf16x4*>(&sA[buf][s][(row0 + RPP * i) * LD + col4 * 4]) = parts[s];
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int c = tid + 256 * i;
+      const int pl = c / (BN * CPR), w = c % (BN * CPR), row = w / CPR, ch = w % CPR;
+      if (c < NCH) *reinterpret_cast<bf16x8*>(&sB[buf][pl][row * LD + ch * 8]) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nk = (p.K + BKT - 1) / BKT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const int ao = (wm * TM * 32 + li) * LD + 8 * lh;
+    const int bo = (wn * TN * 32 + li) * LD + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks) {
+      bf16x8 fa[TM][NS], fb[TN][NS];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          fa[a][s] = *reinterpret_cast<const bf16x8*>(&sA[buf][s][ao + a * 32 * LD + ks * 16]);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          fb[b][s] = *reinterpret_cast<const bf16x8*>(&sB[buf][s][bo + b * 32 * LD + ks * 16]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) mfma_split<NS>(fa[a], fb[b], acc[a][b]);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  igemm_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, li, lh);
 }
 
 // one thread per output element; the self-check restatement of the above
@@ -225,57 +328,16 @@ __global__ void conv_naive_kernel(ConvK p) {
   }
 }
 
-int fill_convk(const mt_conv* d, ConvK* k) {
-  MT_REQUIRE(d, "mt_conv: null descriptor");
-  MT_REQUIRE(mt_view_ok(&d->x) && mt_view_ok(&d->y), "mt_conv: x/y view invalid (need 16B-aligned pointer, C%%4==0, strides%%4==0)");
-  MT_REQUIRE(d->wt && (reinterpret_cast<uintptr_t>(d->wt) & 15) == 0, "mt_conv: weights null/unaligned");
-  MT_REQUIRE(d->stride == 1 || d->stride == 2, "mt_conv: stride must be 1 or 2 (got %d)", d->stride);
-  MT_REQUIRE(d->KH > 0 && d->KW > 0 && d->pad >= 0 && d->ups >= 0 && d->ups <= 2, "mt_conv: bad kernel/pad/ups");
-  MT_REQUIRE(d->ups == 0 || (d->stride == 1 && !d->transposed), "mt_conv: ups needs stride 1, non-transposed");
-  MT_REQUIRE(d->x.N == d->y.N, "mt_conv: batch mismatch %d vs %d", d->x.N, d->y.N);
-  const int HL = d->x.H << d->ups, WL = d->x.W << d->ups;
-  if (!d->transposed) {
-    int ho = (HL + 2 * d->pad - d->KH) / d->stride + 1, wo = (WL + 2 * d->pad - d->KW) / d->stride + 1;
-    MT_REQUIRE(ho == d->y.H && wo == d->y.W, "mt_conv: output %dx%d does not match conv geometry %dx%d", d->y.H, d->y.W, ho, wo);
-  } else {
-    // y is the larger tensor: conv(y) must map back onto x's logical size
-    int hi = (d->y.H + 2 * d->pad - d->KH) / d->stride + 1, wi = (d->y.W + 2 * d->pad - d->KW) / d->stride + 1;
-    MT_REQUIRE(hi == HL && wi == WL, "mt_conv(transposed): y %dx%d is not a pre-image of x %dx%d", d->y.H, d->y.W, HL, WL);
-  }
-  MT_REQUIRE((int64_t)d->y.N * d->y.H * d->y.W < (1ll << 31), "mt_conv: too many pixels");
-  if (d->res.p) MT_REQUIRE(mt_view_flat(&d->res) && d->res.C >= d->y.C, "mt_conv: residual view invalid");
-  if (d->dsrc.p) MT_REQUIRE(mt_view_flat(&d->dsrc) && d->dsrc.C >= d->y.C, "mt_conv: dsrc view invalid");
-  k->xni = d->x.n_in; k->xsg = d->x.sg; k->yni = d->y.n_in; k->ysg = d->y.sg;
-  k->x = d->x.p; k->xsn = d->x.sn; k->xsh = d->x.sh; k->xsw = d->x.sw; k->H = d->x.H; k->W = d->x.W; k->C = d->x.C;
-  k->wt = d->wt; k->bias = d->bias;
-  k->y = d->y.p; k->ysn = d->y.sn; k->ysh = d->y.sh; k->ysw = d->y.sw; k->Ho = d->y.H; k->Wo = d->y.W; k->Co = d->y.C;
-  k->N = d->x.N; k->KH = d->KH; k->KW = d->KW; k->stride = d->stride; k->pad = d->pad; k->transposed = d->transposed; k->ups = d->ups;
-  k->M = d->y.N * d->y.H * d->y.W; k->K = d->KH * d->KW * d->x.C;
-  k->act = d->act; k->alpha = d->alpha;
-  k->res = d->res.p; k->rsn = d->res.sn; k->rsh = d->res.sh; k->rsw = d->res.sw; k->beta = d->beta;
-  k->ds = d->dsrc.p; k->dsn = d->dsrc.sn; k->dsh = d->dsrc.sh; k->dsw = d->dsrc.sw; k->dact = d->dact; k->dact_c0 = d->dact_c0;
-  k->accumulate = d->accumulate;
-  k->zb = 1; k->zdiv = 1; k->xz = k->wz = k->yz = 0;
-  return MT_OK;
-}
-
 template <int WGM, int WGN, int TM, int TN>
-void launch_igemm(const ConvK& k, hipStream_t s) {
+void launch_igemm(const ConvK& k, hipStream_t s, int prec = MT_PREC_F32) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   dim3 grid((k.M + BM - 1) / BM, (k.Co + BN - 1) / BN, k.zb);
-  hipLaunchKernelGGL((igemm_kernel<WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
+  if (prec == MT_PREC_BF16X3) hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 2>), grid, dim3(256), 0, s, k);
+  else if (prec == MT_PREC_BF16X6) hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 3>), grid, dim3(256), 0, s, k);
+  else hipLaunchKernelGGL((igemm_kernel<WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
 }
 
 // ------------------------------------------------------------------ wgrad --
-struct WgK {
-  const float* d; long dsn, dsh, dsw; int Hd, Wd, Cd;
-  const float* g; long gsn, gsh, gsw; int Hg, Wg, Cg;
-  int dni; long dsg; int gni; long gsg;
-  int KH, KW, stride, pad, ups;
-  int M, per_split;   // pixels, pixels per split (multiple of 32)
-  int atiles, btiles;
-  float* slabs;
-};
 
 // dW[a][tap][b] partial over one pixel range.  GEMM with K = pixels: both
 // operands are pixel-major, so LDS tiles are [32 pixels][channels] and the
@@ -391,6 +453,184 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgK p) {
     }
 }
 
+// Split-bf16 weight gradient: K = pixels.  Both operands are pixel-major in
+// HBM, so the staging pass transposes while it splits: one task = (pixel pair,
+// 4-channel group) -> two 16-B loads, and per channel and plane ONE 32-bit LDS
+// store of the two neighbouring pixels, into [channel][pixel] tiles that the
+// MFMA operands then read along k with ds_read_b128.
+template <int WGM, int WGN, int TM, int TN, int NS>
+__global__ __launch_bounds__(256) void wgrad_split_kernel(WgK p) {
+  constexpr int BKT = NS == 3 ? 16 : 32;                        // pixels per LDS stage
+  constexpr int LD = BKT + 8, PPN = BKT / 2;                    // pixel pairs per stage
+  constexpr int BMA = WGM * TM * 32, BNB = WGN * TN * 32;
+  constexpr int TA = PPN * (BMA / 4), TB = PPN * (BNB / 4);     // staging tasks per stage
+  constexpr int RA = (TA + 255) / 256, RB = (TB + 255) / 256;
+  __shared__ __attribute__((aligned(16))) __bf16 sD[2][NS][BMA * LD];
+  __shared__ __attribute__((aligned(16))) __bf16 sG[2][NS][BNB * LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN, li = lane & 31, lh = lane >> 5;
+  int bid = blockIdx.x;
+  const int bt = bid % p.btiles; bid /= p.btiles;
+  const int at = bid % p.atiles; bid /= p.atiles;
+  const int tap = bid;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int a0 = at * BMA, b0 = bt * BNB;
+  const int split = blockIdx.y;
+  const int pbeg = split * p.per_split;
+  const int pend = min(p.M, pbeg + p.per_split);
+  const int HWd = p.Hd * p.Wd;
+  const int HL = p.Hg << p.ups, WL = p.Wg << p.ups;
+
+  f32x4 rd[RA][2], rg[RB][2];
+  auto load_chunk = [&](int pix0) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int t = tid + 256 * i, pp = t % PPN, cg = t / PPN;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int pidx = pix0 + 2 * pp + e;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < TA && pidx < pend && a0 + 4 * cg < p.Cd) {
+          int n = pidx / HWd, rem = pidx - n * HWd, y = rem / p.Wd, x = rem - y * p.Wd;
+          v = *reinterpret_cast<const f32x4*>(p.d + (long)(n / p.dni) * p.dsg + (long)(n % p.dni) * p.dsn +
+                                              (long)y * p.dsh + (long)x * p.dsw + a0 + 4 * cg);
+        }
+        rd[i][e] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int t = tid + 256 * i, pp = t % PPN, cg = t / PPN;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int pidx = pix0 + 2 * pp + e;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t < TB && pidx < pend && b0 + 4 * cg < p.Cg) {
+          int n = pidx / HWd, rem = pidx - n * HWd, y = rem / p.Wd, x = rem - y * p.Wd;
+          int iy = y * p.stride - p.pad + kh, ix = x * p.stride - p.pad + kw;
+          if ((unsigned)iy < (unsigned)HL && (unsigned)ix < (unsigned)WL) {
+            iy >>= p.ups; ix >>= p.ups;
+            v = *reinterpret_cast<const f32x4*>(p.g + (long)(n / p.gni) * p.gsg + (long)(n % p.gni) * p.gsn +
+                                                (long)iy * p.gsh + (long)ix * p.gsw + b0 + 4 * cg);
+          }
+        }
+        rg[i][e] = v;
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int t = tid + 256 * i, pp = t % PPN, cg = t / PPN;
+      if (t < TA) {
+        bf16x4 p0[NS], p1[NS];
+        split4<NS>(rd[i][0], p0);
+        split4<NS>(rd[i][1], p1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            bf16x2 v = {p0[s][c], p1[s][c]};
+            *reinterpret_cast<bf16x2*>(&sD[buf][s][(4 * cg + c) * LD + 2 * pp]) = v;
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int t = tid + 256 * i, pp = t % PPN, cg = t / PPN;
+      if (t < TB) {
+        bf16x4 p0[NS], p1[NS];
+        split4<NS>(rg[i][0], p0);
+        split4<NS>(rg[i][1], p1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            bf16x2 v = {p0[s][c], p1[s][c]};
+            *reinterpret_cast<bf16x2*>(&sG[buf][s][(4 * cg + c) * LD + 2 * pp]) = v;
+          }
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunks = pend > pbeg ? (pend - pbeg + BKT - 1) / BKT : 0;
+  if (nchunks > 0) {
+    load_chunk(pbeg);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunks) load_chunk(pbeg + (ch + 1) * BKT);
+    const int ao = (wm * TM * 32 + li) * LD + 8 * lh;
+    const int bo = (wn * TN * 32 + li) * LD + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ++ks) {
+      bf16x8 fa[TM][NS], fb[TN][NS];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          fa[a][s] = *reinterpret_cast<const bf16x8*>(&sD[buf][s][ao + a * 32 * LD + ks * 16]);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          fb[b][s] = *reinterpret_cast<const bf16x8*>(&sG[buf][s][bo + b * 32 * LD + ks * 16]);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) mfma_split<NS>(fa[a], fb[b], acc[a][b]);
+    }
+    if (ch + 1 < nchunks) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+  const int T = p.KH * p.KW;
+  float* slab = p.slabs + (long)split * p.Cd * T * p.Cg;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ai = a0 + wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ai >= p.Cd) continue;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int bi = b0 + wn * TN * 32 + b * 32 + li;
+        if (bi < p.Cg) slab[((long)ai * T + tap) * p.Cg + bi] = acc[a][b][r];
+      }
+    }
+}
+
+// packed weights for the split paths: dst[plane][a][Kp], plane s = s-th bf16
+// term, Kp = row length padded to a multiple of 32 with zeros
+__global__ void weight_pack_split_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
+                                         int AP, int BP, int Kp, int NS, int flip) {
+  const long total = (long)AP * Kp;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % Kp);
+    const int a = (int)(e / Kp);
+    float v = 0.f;
+    if (k < T * BP) {
+      const int t = k / BP, b = k - t * BP;
+      if (a < A && b < B) v = src[a * sa + b * sb + (flip ? T - 1 - t : t) * st];
+    }
+    for (int s = 0; s < NS; ++s) {
+      const __bf16 h = (__bf16)v;
+      dst[s * total + e] = h;
+      v -= (float)h;
+    }
+  }
+}
+
 __global__ void wgrad_reduce_kernel(const float* slabs, int splits, int AP, int T, int BP, float* dst,
                                     int A, int B, long sa, long sb, long st, int accumulate) {
   const long per = (long)AP * T * BP;
@@ -468,14 +708,20 @@ int wgrad_cfg(const mt_wgrad* d, int* atiles, int* btiles, int* cfg) {
 
 }  // namespace
 
+int mt_halo_try_launch(const mt_conv* d, void* stream);   // conv_halo.hip
+
 extern "C" int mt_conv_run(const mt_conv* d, void* stream) {
+  if (d && d->algo == MT_ALGO_AUTO && mt_halo_try_launch(d, stream)) return mt_check_launch("mt_conv_run(halo)");
   ConvK k;
   int rc = fill_convk(d, &k);
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (k.Co > 64) launch_igemm<2, 2, 2, 2>(k, s);        // 128 x 128
-  else if (k.Co > 32) launch_igemm<2, 2, 2, 1>(k, s);   // 128 x 64
-  else launch_igemm<4, 1, 1, 1>(k, s);                  // 128 x 32
+  const int prec = d->precision;
+  MT_REQUIRE(prec == MT_PREC_F32 || prec == MT_PREC_BF16X3 || prec == MT_PREC_BF16X6, "mt_conv: unknown precision %d", prec);
+  if (prec != MT_PREC_F32) k.Kp = ((k.K + 31) / 32) * 32;
+  if (k.Co > 64) launch_igemm<2, 2, 2, 2>(k, s, prec);        // 128 x 128
+  else if (k.Co > 32) launch_igemm<2, 2, 2, 1>(k, s, prec);   // 128 x 64
+  else launch_igemm<4, 1, 1, 1>(k, s, prec);                  // 128 x 32
   return mt_check_launch("mt_conv_run");
 }
 
@@ -516,12 +762,20 @@ extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
   wgrad_cfg(d, &k.atiles, &k.btiles, &cfg);
   dim3 grid(k.atiles * k.btiles * d->KH * d->KW, d->splits);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  switch (cfg) {
-    case 0: hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, k); break;
-    case 1: hipLaunchKernelGGL((wgrad_kernel<2, 2, 1, 1>), grid, dim3(256), 0, s, k); break;
-    case 2: hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 1>), grid, dim3(256), 0, s, k); break;
-    default: hipLaunchKernelGGL((wgrad_kernel<4, 1, 1, 1>), grid, dim3(256), 0, s, k); break;
+  MT_REQUIRE(d->precision >= MT_PREC_F32 && d->precision <= MT_PREC_BF16X6, "mt_wgrad: unknown precision");
+#define MT_WG_LAUNCH(KERN, ...)                                                                         \
+  switch (cfg) {                                                                                        \
+    case 0: hipLaunchKernelGGL((KERN<2, 2, 2, 2 __VA_ARGS__>), grid, dim3(256), 0, s, k); break;        \
+    case 1: hipLaunchKernelGGL((KERN<2, 2, 1, 1 __VA_ARGS__>), grid, dim3(256), 0, s, k); break;        \
+    case 2: hipLaunchKernelGGL((KERN<1, 4, 1, 1 __VA_ARGS__>), grid, dim3(256), 0, s, k); break;        \
+    default: hipLaunchKernelGGL((KERN<4, 1, 1, 1 __VA_ARGS__>), grid, dim3(256), 0, s, k); break;       \
   }
+#define MT_COMMA ,
+  if (d->precision == MT_PREC_BF16X3) { MT_WG_LAUNCH(wgrad_split_kernel, MT_COMMA 2) }
+  else if (d->precision == MT_PREC_BF16X6) { MT_WG_LAUNCH(wgrad_split_kernel, MT_COMMA 3) }
+  else { MT_WG_LAUNCH(wgrad_kernel) }
+#undef MT_WG_LAUNCH
+#undef MT_COMMA
   return mt_check_launch("mt_wgrad_run");
 }
 
@@ -596,4 +850,17 @@ extern "C" int mt_corr_masked(const mt_view* ft, const mt_view* fr, const float*
   k.zb = B * R; k.zdiv = R; k.xz = (long)P * C; k.wz = (long)P * C; k.yz = (long)P * P;
   launch_igemm<2, 2, 2, 1>(k, static_cast<hipStream_t>(stream));
   return mt_check_launch("mt_corr_masked");
+}
+
+extern "C" int mt_weight_pack_split(const float* src, int32_t A, int32_t B, int32_t T, int64_t sa, int64_t sb,
+                                    int64_t st, void* dst, int32_t AP, int32_t BP, int32_t precision, int32_t flip,
+                                    void* stream) {
+  MT_REQUIRE(src && dst && A <= AP && B <= BP && (BP & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
+             "mt_weight_pack_split: bad arguments");
+  MT_REQUIRE(precision == MT_PREC_BF16X3 || precision == MT_PREC_BF16X6, "mt_weight_pack_split: precision");
+  const int Kp = ((T * BP + 31) / 32) * 32;
+  hipLaunchKernelGGL(weight_pack_split_kernel, dim3(mt_grid_1d((int64_t)AP * Kp, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, A, B, T, (long)sa, (long)sb, (long)st,
+                     reinterpret_cast<__bf16*>(dst), AP, BP, Kp, precision == MT_PREC_BF16X6 ? 3 : 2, flip);
+  return mt_check_launch("mt_weight_pack_split");
 }

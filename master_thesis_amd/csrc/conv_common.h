@@ -1,0 +1,146 @@
+// Shared device/host pieces of the convolution engine (conv.hip, conv_halo.hip).
+#pragma once
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;
+
+struct ConvK {
+  const float* x; long xsn, xsh, xsw; int H, W, C;   // physical dims of the gathered tensor
+  int xni; long xsg; int yni; long ysg;              // two-level image index of x and y
+  const float* wt; const float* bias;
+  float* y; long ysn, ysh, ysw; int Ho, Wo, Co;
+  int N, KH, KW, stride, pad, transposed, ups;
+  int M, K;
+  int act; float alpha;
+  const float* res; long rsn, rsh, rsw; float beta;
+  const float* ds; long dsn, dsh, dsw; int dact, dact_c0;
+  int accumulate;
+  int zb, zdiv; long xz, wz, yz;   // batched GEMM over blockIdx.z (correlation)
+  int Kp;                          // bf16x3 path: padded row length of the packed weights
+};
+
+// Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give
+// each XCD a contiguous band of pixel tiles so that the rows two neighbouring
+// tiles both gather (3x3 / 5x5 halos) are served by one L2.  Bijective for
+// any tile count; placement is a speed matter only.
+__device__ __forceinline__ int xcd_remap(int bid, int nt) {
+  const int q = nt >> 3, r = nt & 7, xcd = bid & 7, local = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                               int li, int lh) {
+  const int HWo = p.Ho * p.Wo;
+  // ---- epilogue -----------------------------------------------------------
+  // C/D layout of the 32x32 tile: col (o) = lane & 31, row (pixel) =
+  // (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= p.M) continue;
+      const int n = m / HWo;
+      const int rem = m - n * HWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const long yo = (long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + (long)oy * p.ysh + (long)ox * p.ysw;
+      const long ro = p.res ? (long)n * p.rsn + (long)oy * p.rsh + (long)ox * p.rsw : 0;
+      const long so = p.ds ? (long)n * p.dsn + (long)oy * p.dsh + (long)ox * p.dsw : 0;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int o = n0 + wn * TN * 32 + b * 32 + li;
+        if (o >= p.Co) continue;
+        float v = acc[a][b][r];
+        if (p.bias) v += p.bias[o];
+        v = mt_act_fn(v, p.act) * p.alpha;
+        if (p.res) v += p.beta * p.res[ro + o];
+        if (p.accumulate) v += p.y[yo + o];
+        if (p.ds && o >= p.dact_c0) v *= mt_dact_fn(p.ds[so + o], p.dact);
+        p.y[yo + o] = v;
+      }
+    }
+  }
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int NS>
+__device__ __forceinline__ void split4(const f32x4& v, bf16x4 (&out)[NS]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float r = v[j];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const __bf16 h = (__bf16)r;
+      out[s][j] = h;
+      r -= (float)h;
+    }
+  }
+}
+
+// acc += sum over the retained partial products, smallest first
+template <int NS>
+__device__ __forceinline__ void mfma_split(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS], f32x16& acc) {
+  if constexpr (NS == 3) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+}
+
+struct WgK {
+  const float* d; long dsn, dsh, dsw; int Hd, Wd, Cd;
+  const float* g; long gsn, gsh, gsw; int Hg, Wg, Cg;
+  int dni; long dsg; int gni; long gsg;
+  int KH, KW, stride, pad, ups;
+  int M, per_split;   // pixels, pixels per split (multiple of 32)
+  int atiles, btiles;
+  float* slabs;
+};
+
+inline int fill_convk(const mt_conv* d, ConvK* k) {
+  MT_REQUIRE(d, "mt_conv: null descriptor");
+  MT_REQUIRE(mt_view_ok(&d->x) && mt_view_ok(&d->y), "mt_conv: x/y view invalid (need 16B-aligned pointer, C%%4==0, strides%%4==0)");
+  MT_REQUIRE(d->wt && (reinterpret_cast<uintptr_t>(d->wt) & 15) == 0, "mt_conv: weights null/unaligned");
+  MT_REQUIRE(d->stride == 1 || d->stride == 2, "mt_conv: stride must be 1 or 2 (got %d)", d->stride);
+  MT_REQUIRE(d->KH > 0 && d->KW > 0 && d->pad >= 0 && d->ups >= 0 && d->ups <= 2, "mt_conv: bad kernel/pad/ups");
+  MT_REQUIRE(d->ups == 0 || (d->stride == 1 && !d->transposed), "mt_conv: ups needs stride 1, non-transposed");
+  MT_REQUIRE(d->x.N == d->y.N, "mt_conv: batch mismatch %d vs %d", d->x.N, d->y.N);
+  const int HL = d->x.H << d->ups, WL = d->x.W << d->ups;
+  if (!d->transposed) {
+    int ho = (HL + 2 * d->pad - d->KH) / d->stride + 1, wo = (WL + 2 * d->pad - d->KW) / d->stride + 1;
+    MT_REQUIRE(ho == d->y.H && wo == d->y.W, "mt_conv: output %dx%d does not match conv geometry %dx%d", d->y.H, d->y.W, ho, wo);
+  } else {
+    // y is the larger tensor: conv(y) must map back onto x's logical size
+    int hi = (d->y.H + 2 * d->pad - d->KH) / d->stride + 1, wi = (d->y.W + 2 * d->pad - d->KW) / d->stride + 1;
+    MT_REQUIRE(hi == HL && wi == WL, "mt_conv(transposed): y %dx%d is not a pre-image of x %dx%d", d->y.H, d->y.W, HL, WL);
+  }
+  MT_REQUIRE((int64_t)d->y.N * d->y.H * d->y.W < (1ll << 31), "mt_conv: too many pixels");
+  if (d->res.p) MT_REQUIRE(mt_view_flat(&d->res) && d->res.C >= d->y.C, "mt_conv: residual view invalid");
+  if (d->dsrc.p) MT_REQUIRE(mt_view_flat(&d->dsrc) && d->dsrc.C >= d->y.C, "mt_conv: dsrc view invalid");
+  k->xni = d->x.n_in; k->xsg = d->x.sg; k->yni = d->y.n_in; k->ysg = d->y.sg;
+  k->x = d->x.p; k->xsn = d->x.sn; k->xsh = d->x.sh; k->xsw = d->x.sw; k->H = d->x.H; k->W = d->x.W; k->C = d->x.C;
+  k->wt = d->wt; k->bias = d->bias;
+  k->y = d->y.p; k->ysn = d->y.sn; k->ysh = d->y.sh; k->ysw = d->y.sw; k->Ho = d->y.H; k->Wo = d->y.W; k->Co = d->y.C;
+  k->N = d->x.N; k->KH = d->KH; k->KW = d->KW; k->stride = d->stride; k->pad = d->pad; k->transposed = d->transposed; k->ups = d->ups;
+  k->M = d->y.N * d->y.H * d->y.W; k->K = d->KH * d->KW * d->x.C;
+  k->act = d->act; k->alpha = d->alpha;
+  k->res = d->res.p; k->rsn = d->res.sn; k->rsh = d->res.sh; k->rsw = d->res.sw; k->beta = d->beta;
+  k->ds = d->dsrc.p; k->dsn = d->dsrc.sn; k->dsh = d->dsrc.sh; k->dsw = d->dsrc.sw; k->dact = d->dact; k->dact_c0 = d->dact_c0;
+  k->accumulate = d->accumulate;
+  k->zb = 1; k->zdiv = 1; k->xz = k->wz = k->yz = 0;
+  return MT_OK;
+}
+
+
+}  // namespace

@@ -7,6 +7,7 @@ heavy op is a libmt355 call on the current HIP stream; torch only owns memory
 and the autograd graph.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -15,10 +16,43 @@ from . import _lib as L
 WEIGHT_EPOCH = 0          # bumped by the optimizer: packed-weight cache key
 _pack_cache = {}
 PROFILE = None            # list -> every conv-engine launch appends (kernel, flops, ev0, ev1)
+# MFMA arithmetic of the conv engine (include/mt355.h, mt_precision):
+#   'bf16x6'  3-term bf16 split, 6 partial products: fp32-equivalent (default)
+#   'bf16x3'  2-term split, 3 partial products: ~4e-6 relative per layer
+#   'f32'     fp32-input MFMA
+PRECISION = os.environ.get('MT355_PRECISION', 'bf16x6')
+USE_HALO = os.environ.get('MT355_HALO', '1') != '0'   # LDS halo-tile kernel for stride-1 3x3/5x5 layers
+_PREC = {'f32': L.PREC_F32, 'bf16x3': L.PREC_BF16X3, 'bf16x6': L.PREC_BF16X6}
+_KTAG = {'f32': '', 'bf16x3': ',2', 'bf16x6': ',3'}
 
 
-def _igemm_name(co):
-    return 'igemm_kernel<2,2,2,2>' if co > 64 else ('igemm_kernel<2,2,2,1>' if co > 32 else 'igemm_kernel<4,1,1,1>')
+def _prec():
+    return _PREC[PRECISION]
+
+
+class precision:
+    """``with precision('bf16x3'): ...`` scoped override."""
+
+    def __init__(self, name):
+        assert name in _PREC, name
+        self.name = name
+
+    def __enter__(self):
+        global PRECISION
+        self.old, PRECISION = PRECISION, self.name
+
+    def __exit__(self, *a):
+        global PRECISION
+        PRECISION = self.old
+
+
+def _igemm_name(co, d=None):
+    cfg = '2,2,2,2' if co > 64 else ('2,2,2,1' if co > 32 else '4,1,1,1')
+    if d is not None and PRECISION != 'f32' and d.algo == 0 and not d.transposed and d.stride == 1 \
+            and d.KH in (3, 5) and d.pad == d.KH // 2 and d.x.C % 8 == 0:
+        return f'igemm_halo_kernel<{d.KH},{_KTAG[PRECISION][1:]},{cfg}>'
+    base = 'igemm_kernel' if PRECISION == 'f32' else 'igemm_split_kernel'
+    return f'{base}<{cfg}{_KTAG[PRECISION]}>'
 
 
 class _Prof:
@@ -76,10 +110,10 @@ def null_view():
 
 
 # ------------------------------------------------------------ weight packs --
-def _pack(w, a_dim, kind):
+def _pack(w, a_dim, kind, flip=False):
     """[AP][T][BP] packed copy of a conv weight.  ``a_dim`` selects which of
     the two leading dims of ``w`` becomes the GEMM's output-channel axis."""
-    key = (w.data_ptr(), w._version, kind, WEIGHT_EPOCH)
+    key = (w.data_ptr(), w._version, kind, PRECISION, WEIGHT_EPOCH)
     hit = _pack_cache.get(key)
     if hit is not None:
         return hit[0]
@@ -90,8 +124,14 @@ def _pack(w, a_dim, kind):
         a, b, sa, sb = d0, d1, d1 * t, t
     else:
         a, b, sa, sb = d1, d0, t, d1 * t
-    out = torch.empty((cpad(a), t, cpad(b)), device=w.device, dtype=torch.float32)
-    L.call('mt_weight_pack', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), L.stream_ptr())
+    if PRECISION != 'f32':
+        kp = (t * cpad(b) + 31) // 32 * 32
+        out = torch.empty((3 if PRECISION == 'bf16x6' else 2, cpad(a), kp), device=w.device, dtype=torch.bfloat16)
+        L.call('mt_weight_pack_split', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _prec(),
+               1 if flip else 0, L.stream_ptr())
+    else:
+        out = torch.empty((cpad(a), t, cpad(b)), device=w.device, dtype=torch.float32)
+        L.call('mt_weight_pack', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), L.stream_ptr())
     # the entry keeps ``w`` alive so that its address cannot be recycled for a
     # different weight while the key is valid (cleared every optimizer step)
     _pack_cache[key] = (out, w)
@@ -149,11 +189,13 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
     d.res = view_of(res) if res is not None else null_view()
     d.beta = beta
     d.dsrc = null_view()
+    d.precision = _prec()
+    d.algo = 0 if USE_HALO else 1
     if spec.kind == 'c':
         flops = 2.0 * n * ho * wo * spec.cin * spec.cout * spec.k * spec.k
     else:
         flops = 2.0 * n * h * w_ * spec.cin * spec.cout * spec.k * spec.k
-    with _Prof(_igemm_name(d.y.C), flops):
+    with _Prof(_igemm_name(d.y.C, d), flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
     return out
 
@@ -164,19 +206,25 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     output)."""
     d = L.Conv()
     d.x, d.y = view_of(dz), yv
-    d.wt = _pack(w, 1 if spec.kind == 'c' else 0, 'b').data_ptr()
+    # the backward-data of a stride-1 "same" Conv2d is itself a stride-1 "same"
+    # convolution with tap-flipped, channel-swapped weights: run it as a forward
+    # conv so that it takes the halo-tile kernel
+    as_fwd = USE_HALO and spec.kind == 'c' and spec.stride == 1 and PRECISION != 'f32' and dz.shape[3] % 8 == 0
+    d.wt = _pack(w, 1 if spec.kind == 'c' else 0, 'bflip' if as_fwd else 'b', flip=as_fwd).data_ptr()
     d.bias = None
     d.KH = d.KW = spec.k
     d.stride, d.pad, d.ups = spec.stride, spec.pad, 0
-    d.transposed = 1 if spec.kind == 'c' else 0
+    d.transposed = 0 if (spec.kind != 'c' or as_fwd) else 1
     d.act, d.alpha = L.ACT_NONE, alpha
     d.res, d.beta = null_view(), 0.0
     d.dsrc = view_of(dsrc) if dsrc is not None else null_view()
     d.dact, d.dact_c0 = dact, dact_c0
     d.accumulate = 1 if accumulate else 0
+    d.precision = _prec()
+    d.algo = 0 if USE_HALO else 1
     side = d.x if spec.kind == 'c' else yv          # the conv's output side
     flops = 2.0 * side.N * side.H * side.W * spec.cin * spec.cout * spec.k * spec.k
-    with _Prof(_igemm_name(yv.C), flops):
+    with _Prof(_igemm_name(yv.C, d), flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
 
 
@@ -212,14 +260,17 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True):
     d.splits = _splits(tiles * t, pixels)
     slabs = torch.empty((d.splits * ap * t * bp,), device=w.device, dtype=torch.float32)
     d.slabs = slabs.data_ptr()
+    d.precision = _prec()
+    wbase = 'wgrad_kernel' if PRECISION == 'f32' else 'wgrad_split_kernel'
     if ap > 64 and bp > 64:
-        kname = 'wgrad_kernel<2,2,2,2>'
+        wcfg = '2,2,2,2'
     elif ap <= 32:
-        kname = 'wgrad_kernel<1,4,1,1>'
+        wcfg = '1,4,1,1'
     elif bp <= 32:
-        kname = 'wgrad_kernel<4,1,1,1>'
+        wcfg = '4,1,1,1'
     else:
-        kname = 'wgrad_kernel<2,2,1,1>'
+        wcfg = '2,2,1,1'
+    kname = f'{wbase}<{wcfg}{_KTAG[PRECISION]}>'
     with _Prof(kname, 2.0 * pixels * spec.cin * spec.cout * t):
         L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
     dw = torch.empty_like(w)

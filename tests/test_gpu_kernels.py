@@ -68,8 +68,17 @@ def _torch_layer(x, w, b, k, stride, kind, act):
     return y
 
 
+@pytest.fixture(params=['f32', 'bf16x3', 'bf16x6'])
+def precision(request):
+    from master_thesis_amd import engine as E
+    old = E.PRECISION
+    E.PRECISION = request.param
+    yield request.param
+    E.PRECISION = old
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv_forward_backward(mt, case):
+def test_conv_forward_backward(mt, case, precision):
     """mt_conv_run (fwd + bwd-data), mt_wgrad_run/reduce, mt_bias_grad vs torch
     fp32 conv2d / conv_transpose2d and its autograd, plus the naive kernel."""
     from master_thesis_amd import engine as E
@@ -113,11 +122,12 @@ def test_conv_forward_backward(mt, case):
     d.KH = d.KW = k
     d.stride, d.pad, d.transposed, d.act, d.alpha = stride, k // 2, 0 if kind == 'c' else 1, act, 1.0
     d.res, d.dsrc = E.null_view(), E.null_view()
-    L.call('mt_conv_run_naive', C.byref(d), L.stream_ptr())
-    assert_close(out2, y4, tol=1e-5, what='naive vs mfma')
+    if precision == 'f32':
+        L.call('mt_conv_run_naive', C.byref(d), L.stream_ptr())
+        assert_close(out2, y4, tol=1e-5, what='naive vs mfma')
 
 
-def test_conv_stack_chain(mt):
+def test_conv_stack_chain(mt, precision):
     """A 3-layer chain with fused ReLU gating in the backward."""
     from master_thesis_amd import engine as E
     from master_thesis_amd import _lib as L
@@ -138,9 +148,14 @@ def test_conv_stack_chain(mt):
     out = E.FromNHWC4Fn.apply(E.conv_stack(E.ToNHWC4Fn.apply(xg), specs, pg), 8)
     assert_close(out, y, what='chain fwd')
     out.backward(gy.to(dev()))
-    assert_close(xg.grad, xr.grad, what='chain dx')
+
+    def l2(a, b):     # a ReLU pre-activation within rounding of 0 may flip: judge in L2, not max
+        return float((a.detach().cpu() - b).norm() / b.norm())
+    # bf16x3 carries ~10x the rounding noise of fp32, hence ~10x the kink flips
+    tol = 2e-2 if precision == 'bf16x3' else 2e-3
+    assert l2(xg.grad, xr.grad) < tol, l2(xg.grad, xr.grad)
     for i, (a, b) in enumerate(zip(pg, pr)):
-        assert_close(a.grad, b.grad, what=f'chain grad {i}')
+        assert l2(a.grad, b.grad) < tol, (i, l2(a.grad, b.grad))
 
 
 def test_correlation(mt, golden):
