@@ -122,6 +122,7 @@ typedef struct {
   int32_t splits;
   float* slabs;
   int32_t precision;  /* mt_precision */
+  int32_t algo;       /* mt_algo */
 } mt_wgrad;
 
 int mt_wgrad_run(const mt_wgrad* d, void* stream);

@@ -32,7 +32,7 @@ class Conv(C.Structure):
 class Wgrad(C.Structure):
     _fields_ = [('d', View), ('g', View), ('KH', i32), ('KW', i32),
                 ('stride', i32), ('pad', i32), ('ups', i32), ('splits', i32),
-                ('slabs', C.c_void_p), ('precision', i32)]
+                ('slabs', C.c_void_p), ('precision', i32), ('algo', i32)]
 
 
 class WarpLayout(C.Structure):

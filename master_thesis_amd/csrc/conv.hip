@@ -739,6 +739,8 @@ extern "C" int64_t mt_wgrad_slab_floats(const mt_wgrad* d) {
   return (int64_t)d->splits * d->d.C * d->KH * d->KW * d->g.C;
 }
 
+int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream);   // conv_halo.hip
+
 extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
   MT_REQUIRE(d && mt_view_ok(&d->d) && mt_view_ok(&d->g), "mt_wgrad: invalid views");
   MT_REQUIRE(d->slabs && d->splits >= 1, "mt_wgrad: slabs/splits");
@@ -748,6 +750,7 @@ extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
   MT_REQUIRE((HL + 2 * d->pad - d->KH) / d->stride + 1 == d->d.H && (WL + 2 * d->pad - d->KW) / d->stride + 1 == d->d.W,
              "mt_wgrad: dense tensor %dx%d is not conv(gathered %dx%d)", d->d.H, d->d.W, HL, WL);
   MT_REQUIRE((int64_t)d->d.N * d->d.H * d->d.W < (1ll << 31), "mt_wgrad: too many pixels");
+  if (d->algo == MT_ALGO_AUTO && mt_wgrad_halo_try_launch(d, stream)) return mt_check_launch("mt_wgrad_run(halo)");
   WgK k;
   k.d = d->d.p; k.dsn = d->d.sn; k.dsh = d->d.sh; k.dsw = d->d.sw; k.Hd = d->d.H; k.Wd = d->d.W; k.Cd = d->d.C;
   k.g = d->g.p; k.gsn = d->g.sn; k.gsh = d->g.sh; k.gsw = d->g.sw; k.Hg = d->g.H; k.Wg = d->g.W; k.Cg = d->g.C;

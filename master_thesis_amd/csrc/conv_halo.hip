@@ -220,3 +220,192 @@ int mt_halo_try_launch(const mt_conv* d, void* stream) {
   else { if (x6) launch_halo<5, 3>(k, s); else launch_halo<5, 2>(k, s); }
   return 1;
 }
+
+// ------------------------------------------------------------ wgrad (halo) --
+// Weight gradient of the same stride-1 layers:
+//   dW[a][kh][kw][b] = sum_pixels D[pix][a] * G[pix + (kh,kw) - pad][b]
+// K = pixels.  A block owns a 64 x 64 (a, b) channel tile and KHB kernel rows
+// (all taps of a 3x3, one row of a 5x5) and walks over 4 x 16 pixel tiles: per
+// tile the D pixels and the G halo patch are loaded ONCE, split once, and
+// stored pixel-major exactly as they sit in HBM; the MFMA operands (which need
+// the pixel axis along k) come out of LDS through ds_read_b64_tr_b16, so a tap
+// is again only a row offset.  One k-step = one 16-pixel tile row.
+namespace {
+
+typedef __bf16 __attribute__((address_space(3))) lds_bf16;
+typedef bf16x4 __attribute__((address_space(3))) lds_bf16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int off, int ld) {
+  // two transposed 4(k) x 16(col) block reads -> this lane's 8 consecutive k
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off + 4 * ld));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int KS, int KHB, int NS, int OCC>
+__global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split,
+                                                            int ntiles) {
+  constexpr int TR = 4, TW = 16, PX = TR * TW;           // pixel tile: 4 rows x 16
+  constexpr int CH = 64, LD = CH + 8;                    // channel tile and LDS row (bf16)
+  constexpr int GH = TR + KHB - 1, GW = TW + KS - 1, GP = GH * GW;
+  constexpr int ND4 = PX * (CH / 4), RD = ND4 / 256;     // float4 loads per thread (D)
+  constexpr int NG4 = GP * (CH / 4), RG = (NG4 + 255) / 256;
+  constexpr int NT = KHB * KS;
+  __shared__ __attribute__((aligned(16))) __bf16 sD[NS][PX * LD];
+  __shared__ __attribute__((aligned(16))) __bf16 sG[NS][GP * LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bid = blockIdx.x;
+  const int bt = bid % p.btiles; bid /= p.btiles;
+  const int at = bid % p.atiles; bid /= p.atiles;
+  const int kh0 = bid * KHB;
+  const int a0 = at * CH, b0 = bt * CH;
+  const int split = blockIdx.y;
+  const int t_beg = split * tiles_per_split, t_end = min(ntiles, t_beg + tiles_per_split);
+  const int HL = p.Hg << p.ups, WL = p.Wg << p.ups;
+
+  // staging coordinates relative to the tile origin
+  int d_ry[RD], d_rx[RD], d_c[RD];
+#pragma unroll
+  for (int i = 0; i < RD; ++i) {
+    const int idx = tid + 256 * i, px = idx / (CH / 4);
+    d_c[i] = (idx % (CH / 4)) * 4; d_ry[i] = px >> 4; d_rx[i] = px & 15;
+  }
+  int g_y[RG], g_x[RG], g_c[RG];
+#pragma unroll
+  for (int i = 0; i < RG; ++i) {
+    const int idx = tid + 256 * i, gp = idx / (CH / 4);
+    g_c[i] = (idx % (CH / 4)) * 4; g_y[i] = gp / GW; g_x[i] = gp - g_y[i] * GW;
+  }
+
+  f32x4 rd[RD], rg[RG];
+  auto load_tile = [&](int t) {
+    const int tx = t % tiles_x, r = t / tiles_x, ty = r % tiles_y, n = r / tiles_y;
+    const int ty0 = ty * TR, tx0 = tx * TW;
+    const float* dp = p.d + (long)(n / p.dni) * p.dsg + (long)(n % p.dni) * p.dsn;
+    const float* gp = p.g + (long)(n / p.gni) * p.gsg + (long)(n % p.gni) * p.gsn;
+#pragma unroll
+    for (int i = 0; i < RD; ++i) {
+      const int y = ty0 + d_ry[i], x = tx0 + d_rx[i];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (y < p.Hd && x < p.Wd && a0 + d_c[i] < p.Cd)
+        v = *reinterpret_cast<const f32x4*>(dp + (long)y * p.dsh + (long)x * p.dsw + a0 + d_c[i]);
+      rd[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+      const int ly = ty0 + g_y[i] + kh0 - p.pad, lx = tx0 + g_x[i] - p.pad;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (tid + 256 * i < NG4 && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL && b0 + g_c[i] < p.Cg)
+        v = *reinterpret_cast<const f32x4*>(gp + (long)(ly >> p.ups) * p.gsh + (long)(lx >> p.ups) * p.gsw + b0 + g_c[i]);
+      rg[i] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < RD; ++i) {
+      bf16x4 parts[NS];
+      split4<NS>(rd[i], parts);
+      const int px = (tid + 256 * i) / (CH / 4);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sD[s][px * LD + d_c[i]]) = parts[s];
+    }
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+      if (tid + 256 * i < NG4) {
+        bf16x4 parts[NS];
+        split4<NS>(rg[i], parts);
+        const int gp = (tid + 256 * i) / (CH / 4);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sG[s][gp * LD + g_c[i]]) = parts[s];
+      }
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposed-read lane coordinates: 16-lane group g = lane >> 4 covers columns
+  // 16*(g&1).., k rows 8*(g>>1) + q (+4); lane 4q+p supplies row q, columns 4p..
+  const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, g1 = (lane >> 4) & 1, lh = lane >> 5;
+  const int a_off = (8 * lh + q) * LD + wm * 32 + 16 * g1 + 4 * pp;
+  const int b_off = (8 * lh + q) * LD + wn * 32 + 16 * g1 + 4 * pp;
+
+  if (t_beg < t_end) load_tile(t_beg);
+  for (int t = t_beg; t < t_end; ++t) {
+    __syncthreads();                          // previous tile's MFMA reads are done
+    store_tile();
+    __syncthreads();
+    if (t + 1 < t_end) load_tile(t + 1);      // in flight during the MFMA phase
+#pragma unroll
+    for (int ks = 0; ks < TR; ++ks) {
+      bf16x8 fa[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) fa[s] = tr_frag(sD[s], a_off + ks * 16 * LD, LD);
+#pragma unroll
+      for (int kh = 0; kh < KHB; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+          bf16x8 fb[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) fb[s] = tr_frag(sG[s], b_off + ((ks + kh) * GW + kw) * LD, LD);
+          mfma_split<NS>(fa, fb, acc[kh * KS + kw]);
+        }
+    }
+  }
+
+  const int T = p.KH * p.KW, li = lane & 31;
+  float* slab = p.slabs + (long)split * p.Cd * T * p.Cg;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tap = (kh0 + t / KS) * KS + (t % KS);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int bi = b0 + wn * 32 + li;
+      if (ai < p.Cd && bi < p.Cg) slab[((long)ai * T + tap) * p.Cg + bi] = acc[t][r];
+    }
+  }
+}
+
+}  // namespace
+
+// Called by mt_wgrad_run: returns 1 if the launch was taken by the halo kernel.
+// `splits` blocks along y each own a contiguous range of pixel tiles.
+int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
+  if (d->precision != MT_PREC_BF16X3 && d->precision != MT_PREC_BF16X6) return 0;
+  if (d->stride != 1 || d->KH != d->KW || (d->KH != 3 && d->KH != 5) || d->pad != d->KH / 2) return 0;
+  WgK k;
+  k.d = d->d.p; k.dsn = d->d.sn; k.dsh = d->d.sh; k.dsw = d->d.sw; k.Hd = d->d.H; k.Wd = d->d.W; k.Cd = d->d.C;
+  k.g = d->g.p; k.gsn = d->g.sn; k.gsh = d->g.sh; k.gsw = d->g.sw; k.Hg = d->g.H; k.Wg = d->g.W; k.Cg = d->g.C;
+  k.dni = d->d.n_in; k.dsg = d->d.sg; k.gni = d->g.n_in; k.gsg = d->g.sg;
+  k.KH = d->KH; k.KW = d->KW; k.stride = 1; k.pad = d->pad; k.ups = d->ups;
+  k.M = d->d.N * d->d.H * d->d.W; k.per_split = 0;
+  k.atiles = (k.Cd + 63) / 64; k.btiles = (k.Cg + 63) / 64;
+  k.slabs = d->slabs;
+  const int tiles_y = (k.Hd + 3) / 4, tiles_x = (k.Wd + 15) / 16;
+  const int ntiles = d->d.N * tiles_y * tiles_x;
+  const int tps = (ntiles + d->splits - 1) / d->splits;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool x6 = d->precision == MT_PREC_BF16X6;
+#ifndef MT_WG3_KHB
+#define MT_WG3_KHB 3
+#endif
+#ifndef MT_WG3_OCC
+#define MT_WG3_OCC 1
+#endif
+  if (d->KH == 3) {
+    dim3 grid(k.atiles * k.btiles * (3 / MT_WG3_KHB), d->splits);
+    if (x6) hipLaunchKernelGGL((wgrad_halo_kernel<3, MT_WG3_KHB, 3, MT_WG3_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<3, MT_WG3_KHB, 2, MT_WG3_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles);
+  } else {
+    dim3 grid(k.atiles * k.btiles * 5, d->splits);
+    if (x6) hipLaunchKernelGGL((wgrad_halo_kernel<5, 1, 3, 2>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<5, 1, 2, 2>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles);
+  }
+  return 1;
+}

@@ -257,7 +257,14 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True):
     d.KH = d.KW = spec.k
     d.stride, d.pad = spec.stride, spec.pad
     d.ups = spec.ups if spec.kind == 'c' else 0
-    d.splits = _splits(tiles * t, pixels)
+    halo = USE_HALO and PRECISION != 'f32' and spec.stride == 1 and spec.k in (3, 5)
+    if halo:   # wgrad_halo_kernel: 64 x 64 channel tiles, all taps (3x3) or one kernel row (5x5) per block
+        blocks = ((ap + 63) // 64) * ((bp + 63) // 64) * (1 if spec.k == 3 else 5)
+        ntiles = dv.N * ((dv.H + 3) // 4) * ((dv.W + 15) // 16)
+        d.splits = max(1, min((1024 + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 512))
+    else:
+        d.splits = _splits(tiles * t, pixels)
+    d.algo = 0 if USE_HALO else 1
     slabs = torch.empty((d.splits * ap * t * bp,), device=w.device, dtype=torch.float32)
     d.slabs = slabs.data_ptr()
     d.precision = _prec()
@@ -271,6 +278,8 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True):
     else:
         wcfg = '2,2,1,1'
     kname = f'{wbase}<{wcfg}{_KTAG[PRECISION]}>'
+    if halo:
+        kname = f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else 1},{_KTAG[PRECISION][1:]}>'
     with _Prof(kname, 2.0 * pixels * spec.cin * spec.cout * t):
         L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
     dw = torch.empty_like(w)
