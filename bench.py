@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-chn', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of a captured hipGraph')
     ap.add_argument('--cpu-seconds', type=float, default=30.0)
     return ap.parse_args()
 
@@ -183,6 +184,20 @@ def main():
         opt.step()
         return loss
 
+    eager_dfpn_step = dfpn_step
+    if not args.no_graph:
+        from master_thesis_amd.graph import GraphedTrainStep
+        # N == 1: the whole step is one graph; N > 1: forward+backward are the
+        # graph, the RCCL all-reduce and the Adam launch follow it
+        gstep = GraphedTrainStep(dfpn, opt, batch, include_optimizer=(world == 1))
+
+        def dfpn_step():   # noqa: F811
+            loss = gstep.step()
+            if world > 1:
+                mdist.sync_gradients(opt)
+                opt.step()
+            return loss
+
     dt = timed_steps(dfpn_step, args.steps, args.warmup, world)
     ms = dt / args.steps * 1e3
     value = frames_per_step * args.steps / dt
@@ -193,13 +208,14 @@ def main():
         'config': {'workload': f'cfg2: DFPN train step (fwd+loss+bwd+allreduce+Adam), frames_n={args.frames}, '
                                f'{args.size}x{args.size}, batch_size={args.batch}/GPU',
                    'global_batch': args.batch * world, 'frames_n': args.frames, 'parallelism': f'dp{world}'},
+        'launch': 'eager' if args.no_graph else 'hipGraph replay of the captured step',
         'step_tflops': TFLOP_PER_STEP['dfpn'] * world / (ms * 1e-3) if (args.batch, args.frames, args.size) == (8, 5, 256) else None,
     }
 
     if rank == 0:
-        agg = kernel_profile(dfpn_step)
+        agg = kernel_profile(eager_dfpn_step)
     else:
-        dfpn_step()
+        eager_dfpn_step()
     if rank == 0:
         tot_ms = sum(a[1] for a in agg.values())
         name, (launches, kms, kfl) = max(agg.items(), key=lambda kv: kv[1][1])
@@ -227,11 +243,30 @@ def main():
             opt_c.step()
             return loss
 
+        eager_chn_step = chn_step
+        if not args.no_graph:
+            gstep_c = GraphedTrainStep(chn, opt_c, batch, include_optimizer=(world == 1))
+
+            def chn_step():   # noqa: F811
+                loss = gstep_c.step()
+                if world > 1:
+                    mdist.sync_gradients(opt_c)
+                    opt_c.step()
+                return loss
+
         dtc = timed_steps(chn_step, args.steps, args.warmup, world)
         out['chn_train_step'] = {
             'workload': f'cfg3: CHN train step (DFPN aligner), frames_n={args.frames}, {args.size}x{args.size}, '
                         f'batch_size={args.batch}/GPU',
             'value': frames_per_step * args.steps / dtc, 'unit': 'frames/s', 'ms_per_step': dtc / args.steps * 1e3}
+        if rank == 0:
+            aggc = kernel_profile(eager_chn_step)
+            out['chn_train_step']['conv_engine_ms_per_step'] = sum(a[1] for a in aggc.values())
+            out['chn_train_step']['kernels'] = {
+                k: {'launches': v[0], 'ms': round(v[1], 3), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
+                for k, v in sorted(aggc.items(), key=lambda kv: -kv[1][1])}
+        else:
+            eager_chn_step()
 
     if rank == 0:
         out['roofline_corr'] = corr_roofline()

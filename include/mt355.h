@@ -123,15 +123,20 @@ typedef struct {
   float* slabs;
   int32_t precision;  /* mt_precision */
   int32_t algo;       /* mt_algo */
+  int32_t with_bias;  /* halo-tile path only: also sum D over the pixels (the
+                         bias gradient when D = dY); the slabs then carry
+                         KH*KW + 1 taps, tap KH*KW / column 0 = those sums */
 } mt_wgrad;
 
 int mt_wgrad_run(const mt_wgrad* d, void* stream);
 int64_t mt_wgrad_slab_floats(const mt_wgrad* d);
-/* dst[a*sa + b*sb + t*st] (+)= sum_s slabs[s][a][t][b], a < A, b < B, t < T;
- * slabs rows are padded to AP x T x BP. */
+/* dst[a*sa + b*sb + t*st] (+)= scale * sum_s slabs[s][a][t][b], a < A, b < B,
+ * t < T; slabs are [splits][AP][TS][BP] with TS = T, or T + 1 when the launch
+ * ran with_bias: then db[a] (+)= scale * sum_s slabs[s][a][T][0]. */
 int mt_wgrad_reduce(const float* slabs, int32_t splits, int32_t AP, int32_t T,
-                    int32_t BP, float* dst, int32_t A, int32_t B, int64_t sa,
-                    int64_t sb, int64_t st, int32_t accumulate, void* stream);
+                    int32_t TS, int32_t BP, float* dst, int32_t A, int32_t B,
+                    int64_t sa, int64_t sb, int64_t st, int32_t accumulate,
+                    float scale, float* db, void* stream);
 /* db[c] (+)= sum_pixels D[n,y,x,c], c < C (ws: >= 256*D.C floats) */
 int mt_bias_grad(const mt_view* d, float* db, int32_t C, float* ws,
                  int32_t accumulate, void* stream);
@@ -272,6 +277,13 @@ int mt_sobel_l1_bwd(const float* a, const float* b, int32_t NP, int32_t H,
 int mt_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                  float beta1, float beta2, float step_size, float inv_bc2_sqrt,
                  float eps, float grad_scale, void* stream);
+
+/* The same update with the step counter and the learning rate on the device
+ * (state = {step, lr}: step is incremented first), so that a captured hipGraph
+ * of the whole training step can be replayed. */
+int mt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
+                     float beta1, float beta2, float eps, float grad_scale,
+                     float* state, void* stream);
 
 #ifdef __cplusplus
 }

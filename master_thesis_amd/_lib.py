@@ -32,7 +32,7 @@ class Conv(C.Structure):
 class Wgrad(C.Structure):
     _fields_ = [('d', View), ('g', View), ('KH', i32), ('KW', i32),
                 ('stride', i32), ('pad', i32), ('ups', i32), ('splits', i32),
-                ('slabs', C.c_void_p), ('precision', i32), ('algo', i32)]
+                ('slabs', C.c_void_p), ('precision', i32), ('algo', i32), ('with_bias', i32)]
 
 
 class WarpLayout(C.Structure):
@@ -60,7 +60,7 @@ SIGNATURES = {
     'mt_conv_run_naive': [_P(Conv), _vp],
     'mt_wgrad_run': [_P(Wgrad), _vp],
     'mt_wgrad_slab_floats': [_P(Wgrad)],
-    'mt_wgrad_reduce': [_vp, i32, i32, i32, i32, _vp, i32, i32, i64, i64, i64, i32, _vp],
+    'mt_wgrad_reduce': [_vp, i32, i32, i32, i32, i32, _vp, i32, i32, i64, i64, i64, i32, f32, _vp, _vp],
     'mt_bias_grad': [_P(View), _vp, i32, _vp, i32, _vp],
     'mt_weight_pack': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, _vp],
     'mt_weight_pack_split': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp],
@@ -83,6 +83,7 @@ SIGNATURES = {
     'mt_sobel_l1_fwd': [_vp, _vp, i32, i32, i32, _vp, _vp],
     'mt_sobel_l1_bwd': [_vp, _vp, i32, i32, i32, _vp, _vp, _vp],
     'mt_adam_step': [_vp, _vp, _vp, _vp, i64, f32, f32, f32, f32, f32, f32, _vp],
+    'mt_adam_step_dev': [_vp, _vp, _vp, _vp, i64, f32, f32, f32, f32, _vp, _vp],
 }
 _RESTYPES = {'mt_last_error': C.c_char_p, 'mt_wgrad_slab_floats': i64}
 

@@ -631,20 +631,40 @@ __global__ void weight_pack_split_kernel(const float* src, int A, int B, int T, 
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* slabs, int splits, int AP, int T, int BP, float* dst,
-                                    int A, int B, long sa, long sb, long st, int accumulate) {
-  const long per = (long)AP * T * BP;
-  const long total = (long)A * T * B;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    int b = (int)(e % B);
-    long r = e / B;
-    int t = (int)(r % T);
-    int a = (int)(r / T);
-    const float* s = slabs + ((long)a * T + t) * BP + b;
+// dst[a][t][b] (+)= sum_s slabs[s][a][t][b]; 256 threads = 64 consecutive
+// elements x 4 interleaved split lanes, combined through LDS.  TS >= T is the
+// slab's tap count: tap T (column 0), when present, holds the bias sums.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int splits, int AP, int T, int TS, int BP,
+                                                           float* dst, int A, int B, long sa, long sb, long st,
+                                                           int accumulate, float scale, float* db) {
+  __shared__ float part[4][64];
+  const long per = (long)AP * TS * BP;
+  const long total = (long)A * TS * B;
+  const int e_l = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  for (long e0 = (long)blockIdx.x * 64; e0 < total; e0 += (long)gridDim.x * 64) {
+    const long e = e0 + e_l;
     float acc = 0.f;
-    for (int i = 0; i < splits; ++i) acc += s[i * per];
-    float* d = dst + a * sa + b * sb + t * st;
-    *d = accumulate ? *d + acc : acc;
+    int b = 0, t = 0, a = 0;
+    if (e < total) {
+      b = (int)(e % B);
+      long r = e / B;
+      t = (int)(r % TS);
+      a = (int)(r / TS);
+      const float* s = slabs + ((long)a * TS + t) * BP + b;
+      for (int i = sl; i < splits; i += 4) acc += s[i * per];
+    }
+    part[sl][e_l] = acc;
+    __syncthreads();
+    if (sl == 0 && e < total) {
+      const float v = (part[0][e_l] + part[1][e_l] + part[2][e_l] + part[3][e_l]) * scale;
+      if (t < T) {
+        float* d = dst + a * sa + b * sb + t * st;
+        *d = accumulate ? *d + v : v;
+      } else if (b == 0 && db) {
+        db[a] = accumulate ? db[a] + v : v;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -672,11 +692,18 @@ __global__ void bias_grad_partial_kernel(const float* d, long dsn, long dsh, lon
 }
 
 __global__ void bias_grad_final_kernel(const float* ws, int nblk, int CP, float* db, int C, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  // 64 channels x 4 partial-sum lanes per block
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
   float s = 0.f;
-  for (int i = 0; i < nblk; ++i) s += ws[(long)i * CP + c];
-  db[c] = accumulate ? db[c] + s : s;
+  if (c < C)
+    for (int i = sl; i < nblk; i += 4) s += ws[(long)i * CP + c];
+  part[sl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    const float v = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    db[c] = accumulate ? db[c] + v : v;
+  }
 }
 
 __global__ void weight_pack_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, float* dst,
@@ -736,7 +763,7 @@ extern "C" int mt_conv_run_naive(const mt_conv* d, void* stream) {
 
 extern "C" int64_t mt_wgrad_slab_floats(const mt_wgrad* d) {
   if (!d) return 0;
-  return (int64_t)d->splits * d->d.C * d->KH * d->KW * d->g.C;
+  return (int64_t)d->splits * d->d.C * (d->KH * d->KW + (d->with_bias ? 1 : 0)) * d->g.C;
 }
 
 int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream);   // conv_halo.hip
@@ -751,6 +778,7 @@ extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
              "mt_wgrad: dense tensor %dx%d is not conv(gathered %dx%d)", d->d.H, d->d.W, HL, WL);
   MT_REQUIRE((int64_t)d->d.N * d->d.H * d->d.W < (1ll << 31), "mt_wgrad: too many pixels");
   if (d->algo == MT_ALGO_AUTO && mt_wgrad_halo_try_launch(d, stream)) return mt_check_launch("mt_wgrad_run(halo)");
+  MT_REQUIRE(!d->with_bias, "mt_wgrad: with_bias is only available on the halo-tile path (stride 1, 3x3/5x5, split precision)");
   WgK k;
   k.d = d->d.p; k.dsn = d->d.sn; k.dsh = d->d.sh; k.dsw = d->d.sw; k.Hd = d->d.H; k.Wd = d->d.W; k.Cd = d->d.C;
   k.g = d->g.p; k.gsn = d->g.sn; k.gsh = d->g.sh; k.gsw = d->g.sw; k.Hg = d->g.H; k.Wg = d->g.W; k.Cg = d->g.C;
@@ -782,13 +810,14 @@ extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
   return mt_check_launch("mt_wgrad_run");
 }
 
-extern "C" int mt_wgrad_reduce(const float* slabs, int32_t splits, int32_t AP, int32_t T, int32_t BP, float* dst,
-                               int32_t A, int32_t B, int64_t sa, int64_t sb, int64_t st, int32_t accumulate,
-                               void* stream) {
-  MT_REQUIRE(slabs && dst && splits >= 1 && A <= AP && B <= BP, "mt_wgrad_reduce: bad arguments");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mt_grid_1d((int64_t)A * T * B, 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), slabs, splits, AP, T, BP, dst, A, B, (long)sa, (long)sb,
-                     (long)st, accumulate);
+extern "C" int mt_wgrad_reduce(const float* slabs, int32_t splits, int32_t AP, int32_t T, int32_t TS, int32_t BP,
+                               float* dst, int32_t A, int32_t B, int64_t sa, int64_t sb, int64_t st, int32_t accumulate,
+                               float scale, float* db, void* stream) {
+  MT_REQUIRE(slabs && dst && splits >= 1 && A <= AP && B <= BP && (TS == T || TS == T + 1),
+             "mt_wgrad_reduce: bad arguments");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mt_grid_1d((int64_t)A * TS * B, 64, 2048)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), slabs, splits, AP, T, TS, BP, dst, A, B, (long)sa, (long)sb,
+                     (long)st, accumulate, scale, db);
   return mt_check_launch("mt_wgrad_reduce");
 }
 
@@ -800,12 +829,12 @@ extern "C" int mt_bias_grad(const mt_view* d, float* db, int32_t C, float* ws, i
   const int rows = 256 / C4 > 0 ? 256 / C4 : 1;
   const int threads = rows * C4;
   int nblk = (M + rows * 8 - 1) / (rows * 8);
-  if (nblk > 256) nblk = 256;
+  if (nblk > 128) nblk = 128;
   if (nblk < 1) nblk = 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(nblk), dim3(threads), rows * d->C * sizeof(float), s, d->p,
                      (long)d->sn, (long)d->sh, (long)d->sw, d->H, d->W, d->C, M, ws);
-  hipLaunchKernelGGL(bias_grad_final_kernel, dim3((C + 63) / 64), dim3(64), 0, s, ws, nblk, d->C, db, C, accumulate);
+  hipLaunchKernelGGL(bias_grad_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, ws, nblk, d->C, db, C, accumulate);
   return mt_check_launch("mt_bias_grad");
 }
 

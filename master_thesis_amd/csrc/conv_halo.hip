@@ -244,7 +244,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int off, int ld) {
 
 template <int KS, int KHB, int NS, int OCC>
 __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split,
-                                                            int ntiles) {
+                                                            int ntiles, int with_bias) {
   constexpr int TR = 4, TW = 16, PX = TR * TW;           // pixel tile: 4 rows x 16
   constexpr int CH = 64, LD = CH + 8;                    // channel tile and LDS row (bf16)
   constexpr int GH = TR + KHB - 1, GW = TW + KS - 1, GP = GH * GW;
@@ -328,6 +328,15 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // bias gradient = sum_pixels D[pix][a]: one more MFMA chain against an
+  // all-ones operand, only in the blocks that own b-tile 0 / kernel row 0
+  const bool do_bias = with_bias && bt == 0 && kh0 == 0;
+  f32x16 acc_bias;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_bias[r] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
   // transposed-read lane coordinates: 16-lane group g = lane >> 4 covers columns
   // 16*(g&1).., k rows 8*(g>>1) + q (+4); lane 4q+p supplies row q, columns 4p..
@@ -346,6 +355,10 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
       bf16x8 fa[NS];
 #pragma unroll
       for (int s = 0; s < NS; ++s) fa[s] = tr_frag(sD[s], a_off + ks * 16 * LD, LD);
+      if (do_bias) {
+#pragma unroll
+        for (int s = NS - 1; s >= 0; --s) acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], ones, acc_bias, 0, 0, 0);
+      }
 #pragma unroll
       for (int kh = 0; kh < KHB; ++kh)
 #pragma unroll
@@ -359,7 +372,15 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
   }
 
   const int T = p.KH * p.KW, li = lane & 31;
-  float* slab = p.slabs + (long)split * p.Cd * T * p.Cg;
+  const int TS = T + (with_bias ? 1 : 0);        // the bias sums travel as one more "tap" (column 0)
+  float* slab = p.slabs + (long)split * p.Cd * TS * p.Cg;
+  if (do_bias && wn == 0 && li == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ai < p.Cd) slab[((long)ai * TS + T) * p.Cg] = acc_bias[r];
+    }
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int tap = (kh0 + t / KS) * KS + (t % KS);
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
     for (int r = 0; r < 16; ++r) {
       const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const int bi = b0 + wn * 32 + li;
-      if (ai < p.Cd && bi < p.Cg) slab[((long)ai * T + tap) * p.Cg + bi] = acc[t][r];
+      if (ai < p.Cd && bi < p.Cg) slab[((long)ai * TS + tap) * p.Cg + bi] = acc[t][r];
     }
   }
 }
@@ -400,12 +421,12 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
 #endif
   if (d->KH == 3) {
     dim3 grid(k.atiles * k.btiles * (3 / MT_WG3_KHB), d->splits);
-    if (x6) hipLaunchKernelGGL((wgrad_halo_kernel<3, MT_WG3_KHB, 3, MT_WG3_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<3, MT_WG3_KHB, 2, MT_WG3_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles);
+    if (x6) hipLaunchKernelGGL((wgrad_halo_kernel<3, MT_WG3_KHB, 3, MT_WG3_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<3, MT_WG3_KHB, 2, MT_WG3_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
   } else {
     dim3 grid(k.atiles * k.btiles * 5, d->splits);
-    if (x6) hipLaunchKernelGGL((wgrad_halo_kernel<5, 1, 3, 2>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<5, 1, 2, 2>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles);
+    if (x6) hipLaunchKernelGGL((wgrad_halo_kernel<5, 1, 3, 2>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<5, 1, 2, 2>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
   }
   return 1;
 }

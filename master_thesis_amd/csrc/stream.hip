@@ -440,6 +440,24 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n
   }
 }
 
+// Adam whose step counter and learning rate live on the device, so that the
+// update can be replayed from a captured hipGraph: state = {step, lr}
+__global__ void adam_tick_kernel(float* state) { state[0] += 1.f; }
+
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long n, float b1, float b2, float eps,
+                                float gs, const float* state) {
+  const float t = state[0], lr = state[1];
+  const float step = lr / (1.f - powf(b1, t)), ibc2 = 1.f / sqrtf(1.f - powf(b2, t));
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float gi = g[i] * gs;
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step * (mi / (sqrtf(vi) * ibc2 + eps));
+  }
+}
+
 // row-wise masked L2 normalisation of NHWC4 features (correlation prologue):
 // out[p][c] = x[p][c]*v[p] / (||x[p]*v[p]||_2 + 1e-9); one wave per pixel row
 __global__ void rownorm_kernel(const float* x, long xn, long xh, long xw, int H, int W, int C, const float* v,
@@ -658,4 +676,13 @@ extern "C" int mt_pack_pairs(const mt_pack_src* srcs, int32_t nsrc, int32_t B, i
   hipLaunchKernelGGL(pack_pairs_kernel, dim3(mt_grid_1d(total, 256)), dim3(256), 0, S_(stream), P, B, R, dst->H, dst->W,
                      dst->p, (long)dst->sn, (long)dst->sh, (long)dst->sw, dst->C);
   return mt_check_launch("mt_pack_pairs");
+}
+
+extern "C" int mt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float beta1, float beta2,
+                                float eps, float grad_scale, float* state, void* stream) {
+  MT_REQUIRE(p && g && m && v && state && n > 0, "mt_adam_step_dev: bad arguments");
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, S_(stream), state);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(mt_grid_1d(n, 256)), dim3(256), 0, S_(stream), p, g, m, v, (long)n, beta1,
+                     beta2, eps, grad_scale, state);
+  return mt_check_launch("mt_adam_step_dev");
 }

@@ -233,7 +233,7 @@ def _splits(blocks_base, pixels):
     return max(1, min(s, 512))
 
 
-def conv_backward_weight(spec, dz, xin_view, w, need_bias=True):
+def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0):
     """(dW, db) of one layer.  dz: (N,Ho,Wo,CoP) gradient wrt the layer's
     pre-activation output; xin_view: mt_view of the layer's input."""
     dzv = view_of(dz)
@@ -261,11 +261,15 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True):
     if halo:   # wgrad_halo_kernel: 64 x 64 channel tiles, all taps (3x3) or one kernel row (5x5) per block
         blocks = ((ap + 63) // 64) * ((bp + 63) // 64) * (1 if spec.k == 3 else 5)
         ntiles = dv.N * ((dv.H + 3) // 4) * ((dv.W + 15) // 16)
-        d.splits = max(1, min((1024 + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 512))
+        d.splits = max(1, min((512 + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 256))
     else:
         d.splits = _splits(tiles * t, pixels)
     d.algo = 0 if USE_HALO else 1
-    slabs = torch.empty((d.splits * ap * t * bp,), device=w.device, dtype=torch.float32)
+    # on the halo path the bias gradient rides along as one more slab "tap"
+    fused_bias = halo and need_bias and spec.kind == 'c'
+    d.with_bias = 1 if fused_bias else 0
+    ts = t + (1 if fused_bias else 0)
+    slabs = torch.empty((d.splits * ap * ts * bp,), device=w.device, dtype=torch.float32)
     d.slabs = slabs.data_ptr()
     d.precision = _prec()
     wbase = 'wgrad_kernel' if PRECISION == 'f32' else 'wgrad_split_kernel'
@@ -283,13 +287,15 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True):
     with _Prof(kname, 2.0 * pixels * spec.cin * spec.cout * t):
         L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
     dw = torch.empty_like(w)
+    db = torch.empty((spec.cout,), device=w.device, dtype=torch.float32) if need_bias else None
     # both Conv2d (O,I,k,k) and ConvTranspose2d (I,O,k,k): a = dim 0, b = dim 1
-    L.call('mt_wgrad_reduce', L.ptr(slabs), d.splits, ap, t, bp, L.ptr(dw), a, b, b * t, t, 1, 0, L.stream_ptr())
-    db = None
-    if need_bias:
-        db = torch.empty((spec.cout,), device=w.device, dtype=torch.float32)
+    L.call('mt_wgrad_reduce', L.ptr(slabs), d.splits, ap, t, ts, bp, L.ptr(dw), a, b, b * t, t, 1, 0, scale,
+           L.ptr(db) if fused_bias else None, L.stream_ptr())
+    if need_bias and not fused_bias:
         ws = torch.empty((256 * dz.shape[3],), device=w.device, dtype=torch.float32)
         L.call('mt_bias_grad', C.byref(dzv), L.ptr(db), spec.cout, L.ptr(ws), 0, L.stream_ptr())
+        if scale != 1.0:
+            db.mul_(scale)
     return dw, db
 
 

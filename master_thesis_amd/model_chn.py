@@ -20,7 +20,7 @@ from . import engine as E
 from . import ops
 from .lightning_shim import LightningModule
 from .optim import FlatAdam
-from .utils import LossesUtils
+from .utils import LossesUtils, take
 
 LRELU, NONE = L.ACT_LRELU, L.ACT_NONE
 
@@ -99,10 +99,7 @@ class RRDBNetFn(torch.autograd.Function):
             return E.LayerSpec('c', cin, cout, 3, stride, NONE, ups)
 
         def wgrad(key, sp, dz, xin, scale=1.0):
-            dw, db = E.conv_backward_weight(sp, dz, E.view_of(xin), P[key + '.weight'])
-            if scale != 1.0:
-                dw.mul_(scale)
-                db.mul_(scale)
+            dw, db = E.conv_backward_weight(sp, dz, E.view_of(xin), P[key + '.weight'], scale=scale)
             G[key + '.weight'], G[key + '.bias'] = dw, db
 
         def bdata(key, sp, dz, dx, **kw):
@@ -255,7 +252,7 @@ class CHN(LightningModule):
         (x, m), y, info = batch
         t, r_list = CHN.get_indexes(x.size(2))
         x_ref_aligned, v_ref_aligned, v_map = self.model_aligner.align(
-            x[:, :, t], m[:, :, t], x[:, :, r_list], m[:, :, r_list])
+            x[:, :, t], m[:, :, t], take(x, 2, r_list), take(m, 2, r_list))
         y_hat, y_hat_comp = self(x[:, :, t], 1 - m[:, :, t], x_ref_aligned, v_ref_aligned, v_map)
         return self.compute_loss(y[:, :, t], (1 - m)[:, :, t], y_hat, y_hat_comp, v_map)
 

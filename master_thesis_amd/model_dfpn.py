@@ -14,7 +14,7 @@ from . import engine as E
 from . import ops
 from .lightning_shim import LightningModule
 from .optim import FlatAdam
-from .utils import FlowsUtils, LossesUtils, TransformsUtils
+from .utils import FlowsUtils, LossesUtils, TransformsUtils, take
 
 RELU, NONE = L.ACT_RELU, L.ACT_NONE
 
@@ -119,7 +119,7 @@ class DFPN(LightningModule):
             feats = vgg.forward4(y4, n_taps=4)[3]                       # (b*f,16,16,512)
             feats = feats.reshape(b, f, 16, 16, feats.shape[3])
             ft = feats[:, t].contiguous()
-            fr = feats[:, r_list].reshape(b * len(r_list), 16, 16, feats.shape[4])
+            fr = take(feats, 1, r_list).reshape(b * len(r_list), 16, 16, feats.shape[4])
             corr_y = ops.correlation(ft, fr, None, None, b, len(r_list)).reshape(b, len(r_list), 16, 16, 16, 16)
         corr_loss = LossesUtils.l1(corr, corr_y)
 
@@ -160,15 +160,16 @@ class DFPN(LightningModule):
         (:358-375) never reach the outputs and are skipped; the 16x16 warp
         (:377-379) and the 16/64 resizes of y feed nothing in compute_loss and
         are returned as None."""
-        corr, flow_16, flow_64, flow_256 = self(x[:, :, t], m[:, :, t], x[:, :, r_list], m[:, :, r_list])
+        x_refs, m_refs = take(x, 2, r_list), take(m, 2, r_list)
+        corr, flow_16, flow_64, flow_256 = self(x[:, :, t], m[:, :, t], x_refs, m_refs)
         v = 1 - m
         x_64 = ops.resize_planar(x, (64, 64), 'bilinear')
         v_64 = ops.resize_planar(v, (64, 64), 'nearest')
-        flow_gt_r = flow_gt[:, r_list]
+        flow_gt_r = take(flow_gt, 1, r_list)
         flow_16_gt = FlowsUtils.resize_flow(flow_gt_r, (16, 16))
         flow_64_gt = FlowsUtils.resize_flow(flow_gt_r, (64, 64))
-        x_64_aligned, _ = FlowsUtils.align_set(x_64[:, :, r_list], v_64[:, :, r_list], flow_64)
-        x_256_aligned, _ = FlowsUtils.align_set(x[:, :, r_list], v[:, :, r_list], flow_256)
+        x_64_aligned, _ = FlowsUtils.align_set(take(x_64, 2, r_list), take(v_64, 2, r_list), flow_64)
+        x_256_aligned, _ = FlowsUtils.align_set(x_refs, 1 - m_refs, flow_256)
         xs, vs, ys = (None, x_64, x), (None, v_64, v), (None, None, y)
         xs_aligned = (None, x_64_aligned, x_256_aligned)
         flows = (flow_16, flow_64, flow_256)

@@ -22,6 +22,8 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.step_count = 0
         self.grad_scale = 1.0          # 1/world_size after a SUM all-reduce
+        # device-resident {step, lr}: lets a captured hipGraph replay the update
+        self.dev_state = torch.tensor([0.0, lr], device=dev, dtype=torch.float32)
         off = 0
         self._slices = []
         with torch.no_grad():
@@ -62,13 +64,24 @@ class FlatAdam(torch.optim.Optimizer):
         g = self.param_groups[0]
         b1, b2 = g['betas']
         self.step_count += 1
-        bc1 = 1.0 - b1 ** self.step_count
-        bc2 = 1.0 - b2 ** self.step_count
-        L.call('mt_adam_step', L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
-               self.flat_p.numel(), b1, b2, g['lr'] / bc1, 1.0 / math.sqrt(bc2), g['eps'], self.grad_scale,
-               L.stream_ptr())
+        if torch.cuda.is_current_stream_capturing():
+            # graph capture: step and lr are read from the device at replay time
+            L.call('mt_adam_step_dev', L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.exp_avg),
+                   L.ptr(self.exp_avg_sq), self.flat_p.numel(), b1, b2, g['eps'], self.grad_scale,
+                   L.ptr(self.dev_state), L.stream_ptr())
+        else:
+            self.dev_state[0] = float(self.step_count)
+            bc1 = 1.0 - b1 ** self.step_count
+            bc2 = 1.0 - b2 ** self.step_count
+            L.call('mt_adam_step', L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.exp_avg),
+                   L.ptr(self.exp_avg_sq), self.flat_p.numel(), b1, b2, g['lr'] / bc1, 1.0 / math.sqrt(bc2), g['eps'],
+                   self.grad_scale, L.stream_ptr())
         E.bump_weight_epoch()
         return loss
+
+    def sync_device_lr(self):
+        """Call after an LR-scheduler step when the update runs from a graph."""
+        self.dev_state[1] = float(self.param_groups[0]['lr'])
 
     def state_dict(self):
         return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,

@@ -7,6 +7,29 @@ import torch
 from . import ops
 
 
+_index_cache = {}
+
+
+def take(x, dim, idx):
+    """x.index_select(dim, idx) for a Python list ``idx`` without building the
+    index tensor from host memory on every call (that H2D copy is not allowed
+    while a hipGraph is being captured): runs of consecutive indices become
+    slices, anything else uses a cached device index."""
+    idx = list(idx)
+    runs, start = [], 0
+    for i in range(1, len(idx) + 1):
+        if i == len(idx) or idx[i] != idx[i - 1] + 1:
+            runs.append((idx[start], idx[i - 1] + 1))
+            start = i
+    if len(runs) <= 2:
+        parts = [x.narrow(dim, a, b - a) for a, b in runs]
+        return parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, dim=dim)
+    key = (x.device, tuple(idx))
+    if key not in _index_cache:
+        _index_cache[key] = torch.tensor(idx, device=x.device, dtype=torch.long)
+    return x.index_select(dim, _index_cache[key])
+
+
 class FlowsUtils:
     @staticmethod
     def align_set(x, v, flow):
