@@ -111,10 +111,15 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  // MFMA row i of 32-pixel group g = tile pixel (2g + (i >> 4), i & 15)
+  // MFMA row i of 32-pixel group g = tile pixel (2g + (i >> 4), px(i)) with
+  // px(i) = i for the first tile row and (i - HW_) & 15 for the second: the
+  // 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) then touch 16
+  // consecutive halo pixels (mod 16) -> 16 distinct 16-B bank slots.  The
+  // epilogue uses the same map.
+  const int apx = li < 16 ? li : ((li - HW_) & 15);
   int a_base[TM];
 #pragma unroll
-  for (int a = 0; a < TM; ++a) a_base[a] = ((2 * (wm * TM + a) + (li >> 4)) * HW_ + (li & 15)) * LD + 8 * lh;
+  for (int a = 0; a < TM; ++a) a_base[a] = ((2 * (wm * TM + a) + (li >> 4)) * HW_ + apx) * LD + 8 * lh;
   const int b_base = (wn * TN * 32 + li) * LD + 8 * lh;
 
   const int nchunk = (p.C + CK - 1) / CK;
@@ -168,8 +173,9 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
+      const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;     // MFMA row -> tile pixel
+      const int i32 = row & 31;
+      const int oy = ty0 + (row >> 4), ox = tx0 + (i32 < 16 ? i32 : ((i32 - HW_) & 15));
       if (oy >= p.Ho || ox >= p.Wo) continue;
       const long yo = (long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + (long)oy * p.ysh + (long)ox * p.ysw;
       const long ro = p.res ? (long)n * p.rsn + (long)oy * p.rsh + (long)ox * p.rsw : 0;
@@ -424,9 +430,15 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
     if (x6) hipLaunchKernelGGL((wgrad_halo_kernel<3, MT_WG3_KHB, 3, MT_WG3_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
     else hipLaunchKernelGGL((wgrad_halo_kernel<3, MT_WG3_KHB, 2, MT_WG3_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
   } else {
-    dim3 grid(k.atiles * k.btiles * 5, d->splits);
-    if (x6) hipLaunchKernelGGL((wgrad_halo_kernel<5, 1, 3, 2>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<5, 1, 2, 2>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
+#ifndef MT_WG5_KHB
+#define MT_WG5_KHB 1
+#endif
+#ifndef MT_WG5_OCC
+#define MT_WG5_OCC 2
+#endif
+    dim3 grid(k.atiles * k.btiles * (5 / MT_WG5_KHB), d->splits);
+    if (x6) hipLaunchKernelGGL((wgrad_halo_kernel<5, MT_WG5_KHB, 3, MT_WG5_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
+    else hipLaunchKernelGGL((wgrad_halo_kernel<5, MT_WG5_KHB, 2, MT_WG5_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
   }
   return 1;
 }

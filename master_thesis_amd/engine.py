@@ -21,6 +21,11 @@ PROFILE = None            # list -> every conv-engine launch appends (kernel, fl
 #   'bf16x3'  2-term split, 3 partial products: ~4e-6 relative per layer
 #   'f32'     fp32-input MFMA
 PRECISION = os.environ.get('MT355_PRECISION', 'bf16x6')
+# convolutions that are never differentiated (the VGG feature passes, the DFPN
+# aligner inside the CHN step: torch.no_grad in the reference, model_dfpn.py:125,
+# 242,510, model_vgg.py:43) may run the cheaper 2-term split: ~4e-6 relative per
+# layer, far inside the 1e-3 output bar, and no gradient ever sees it
+PRECISION_NOGRAD = os.environ.get('MT355_PRECISION_NOGRAD', 'bf16x3')
 USE_HALO = os.environ.get('MT355_HALO', '1') != '0'   # LDS halo-tile kernel for stride-1 3x3/5x5 layers
 _PREC = {'f32': L.PREC_F32, 'bf16x3': L.PREC_BF16X3, 'bf16x6': L.PREC_BF16X6}
 _KTAG = {'f32': '', 'bf16x3': ',2', 'bf16x6': ',3'}
@@ -28,6 +33,13 @@ _KTAG = {'f32': '', 'bf16x3': ',2', 'bf16x6': ',3'}
 
 def _prec():
     return _PREC[PRECISION]
+
+
+def nograd_precision():
+    """Precision for a forward pass that keeps no autograd state."""
+    if PRECISION == 'f32' or PRECISION_NOGRAD == 'same':
+        return PRECISION
+    return PRECISION_NOGRAD
 
 
 class precision:
@@ -82,7 +94,9 @@ def bump_weight_epoch():
 
 
 def cpad(c):
-    return (c + 3) // 4 * 4
+    """Channel padding of engine tensors: a multiple of 8 (the ABI needs 4; 8
+    makes every stride-1 3x3/5x5 layer eligible for the halo-tile kernels)."""
+    return (c + 7) // 8 * 8
 
 
 def view_of(t):
@@ -317,6 +331,18 @@ class ConvStackFn(torch.autograd.Function):
         assert x.is_contiguous() and x.dim() == 4
         acts = [x]
         cur = x
+        keep = any(ctx.needs_input_grad)
+        with precision(PRECISION if keep else nograd_precision()):
+            cur = ConvStackFn._run(specs, params, cur, acts)
+        ctx.specs = specs
+        # Function.forward always runs with grad disabled: keep the saved
+        # activations only when something upstream needs a gradient
+        ctx.acts = acts if keep else None
+        ctx.save_for_backward(*params)
+        return cur
+
+    @staticmethod
+    def _run(specs, params, cur, acts):
         for i, sp in enumerate(specs):
             assert sp.ups == 0
             w, b = params[2 * i], params[2 * i + 1]
@@ -327,11 +353,6 @@ class ConvStackFn(torch.autograd.Function):
                 xv, shape = view_of(cur), cur.shape[:3]
             cur = conv_forward(sp, xv, shape, w, b)
             acts.append(cur)
-        ctx.specs = specs
-        # Function.forward always runs with grad disabled: keep the saved
-        # activations only when something upstream needs a gradient
-        ctx.acts = acts if any(ctx.needs_input_grad) else None
-        ctx.save_for_backward(*params)
         return cur
 
     @staticmethod
@@ -371,7 +392,7 @@ def to_nhwc4(x, scale=None, shift=None, cp=None):
     """(N,C,H,W) (any strides) -> (N,H,W,Cp) with optional per-channel affine."""
     n, c, h, w = x.shape
     out = torch.empty((n, h, w, cp or cpad(c)), device=x.device, dtype=torch.float32)
-    if out.shape[3] > cpad(c):
+    if out.shape[3] > (c + 3) // 4 * 4:     # the kernel writes whole groups of 4 channels
         out.zero_()
     ov = view_of(out)
     L.call('mt_nchw_to_nhwc4', L.ptr(x), x.stride(0), x.stride(1), x.stride(2), x.stride(3), n, c, h, w,

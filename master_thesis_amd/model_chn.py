@@ -36,10 +36,18 @@ class RRDBNetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x4, net, names, *params):
+        keep = any(ctx.needs_input_grad)
+        with E.precision(E.PRECISION if keep else E.nograd_precision()):
+            out, saved = RRDBNetFn._run(x4, net, names, params, keep)
+        ctx.saved, ctx.net, ctx.names = saved, net, names
+        ctx.save_for_backward(*params)
+        return out
+
+    @staticmethod
+    def _run(x4, net, names, params, keep):
         P = dict(zip(names, params))
         nf, gc, nb = net.nf, net.gc, net.nb
         cw = nf + 4 * gc
-        keep = any(ctx.needs_input_grad)
         saved = {}
 
         def conv(key, xin, cin, cout, stride=1, act=NONE, ups=0, out=None, res=None, alpha=1.0, beta=0.0):
@@ -83,9 +91,7 @@ class RRDBNetFn(torch.autograd.Function):
         out = conv('conv_last', hr, nf, net.out_nc)                              # (:555)
         if keep:
             saved = dict(first=first, bufs=bufs, z=buf, y=y, u1=u1, u2=u2, hr=hr)
-        ctx.saved, ctx.net, ctx.names = saved, net, names
-        ctx.save_for_backward(*params)
-        return out
+        return out, saved
 
     @staticmethod
     def backward(ctx, dout):

@@ -114,7 +114,7 @@ class DFPN(LightningModule):
                 y_in = ops.resize_planar(y_in, (256, 256), 'bilinear')
             vgg = self.model_vgg
             scale, shift = vgg._affine(y_in.device)
-            y4 = torch.empty((b * f, 256, 256, 4), device=y_in.device, dtype=torch.float32)
+            y4 = torch.empty((b * f, 256, 256, E.cpad(3)), device=y_in.device, dtype=torch.float32)
             E.pack_images(y4, b, f, [(y_in, 0, scale, shift)])
             feats = vgg.forward4(y4, n_taps=4)[3]                       # (b*f,16,16,512)
             feats = feats.reshape(b, f, 16, 16, feats.shape[3])
@@ -207,7 +207,7 @@ class CorrelationVGG(nn.Module):
         b, c, ref_n, h, w = x_refs.size()
         with torch.no_grad():
             # one VGG pass over the target and all reference frames (N = B + B*R)
-            x4 = torch.empty((b + b * ref_n, h, w, 4), device=x_refs.device, dtype=torch.float32)
+            x4 = torch.empty((b + b * ref_n, h, w, E.cpad(3)), device=x_refs.device, dtype=torch.float32)
             E.pack_images(x4[:b], b, 1, [(x_target, 0, scale, shift)])
             E.pack_images(x4[b:], b, ref_n, [(x_refs, 0, scale, shift)])
             feats = self.model_vgg.forward4(x4, n_taps=4)[3]
@@ -270,8 +270,8 @@ class SeparableConv4d(nn.Module):
         s1, p1 = _specs_from(self.conv_1)
         s2, p2 = _specs_from(self.conv_2)
         s2[0].swap_groups = g
-        out = E.conv_stack(x4, s1 + s2, p1 + p2)              # [(g, p_r)][p_t][4]
-        vol = out.reshape(g, p, p, 4)[..., 0]                  # [g][p_r][p_t]
+        out = E.conv_stack(x4, s1 + s2, p1 + p2)              # [(g, p_r)][p_t][Cp]
+        vol = out.reshape(g, p, p, out.shape[3])[..., 0]       # [g][p_r][p_t]
         # (:625-626) [b,r,h_r,w_r,h_t,w_t] -> [b,r,h_t,w_t,h_r,w_r]
         return vol.reshape(b, r, side, side, side, side).permute(0, 1, 4, 5, 2, 3)
 

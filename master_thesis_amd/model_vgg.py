@@ -44,6 +44,11 @@ class VGGFeatures(nn.Module):
         """NHWC4 in (N,H,W,4: already normalised) -> list of NHWC4 taps.  Stops
         after tap ``n_taps`` (DFPN only needs pool4, model_dfpn.py:516-518)."""
         taps, cur = [], x4
+        with E.precision(E.nograd_precision()):
+            return self._forward4(cur, n_taps)
+
+    def _forward4(self, cur, n_taps):
+        taps = []
         for layer in self.features:
             if isinstance(layer, nn.Conv2d):
                 spec = E.LayerSpec('c', layer.in_channels, layer.out_channels, 3, 1, L.ACT_RELU)

@@ -126,7 +126,7 @@ def _src(t, sb, sr, sc, sy, sx, c, c_off, scale=None, shift=None):
 
 class PackFlowEstimatorFn(torch.autograd.Function):
     """The 10-channel FlowEstimator input (model_dfpn.py:733-741) written
-    straight into a (B*R, H, W, 12) NHWC4 tensor; the images are normalised on
+    straight into a (B*R, H, W, cpad(10)) NHWC4 tensor; the images are normalised on
     the fly ((x-mean)/std, model_dfpn.py:71-72).  Differentiable wrt flow_pre."""
 
     @staticmethod
@@ -135,7 +135,7 @@ class PackFlowEstimatorFn(torch.autograd.Function):
         x_t, m_t, x_r, m_r = x_t.contiguous(), m_t.contiguous(), x_r.contiguous(), m_r.contiguous()
         flow_pre = flow_pre.contiguous()
         b, c, r, h, w = x_r.shape
-        out = torch.empty((b * r, h, w, 12), device=x_r.device, dtype=torch.float32)
+        out = torch.empty((b * r, h, w, cpad(10)), device=x_r.device, dtype=torch.float32)
         hw = h * w
         srcs = (L.PackSrc * 5)(
             _src(x_r, c * r * hw, hw, r * hw, w, 1, 3, 0, scale, shift),
@@ -156,12 +156,12 @@ class PackFlowEstimatorFn(torch.autograd.Function):
 
 
 def pack_chn_input(x_t, v_t, x_ra, v_ra, v_maps, scale, shift):
-    """The 9-channel CHN input (model_chn.py:70-80) as (B*R, H, W, 12) NHWC4."""
+    """The 9-channel CHN input (model_chn.py:70-80) as (B*R, H, W, cpad(9)) NHWC4."""
     _chk(x_t, v_t, x_ra, v_ra, v_maps)
     x_t, v_t, x_ra, v_ra, v_maps = (t.contiguous() for t in (x_t, v_t, x_ra, v_ra, v_maps))
     b, c, r, h, w = x_ra.shape
     hw = h * w
-    out = torch.empty((b * r, h, w, 12), device=x_ra.device, dtype=torch.float32)
+    out = torch.empty((b * r, h, w, cpad(9)), device=x_ra.device, dtype=torch.float32)
     srcs = (L.PackSrc * 5)(
         _src(x_t, c * hw, 0, hw, w, 1, 3, 0, scale, shift),
         _src(x_ra, c * r * hw, hw, r * hw, w, 1, 3, 3, scale, shift),

@@ -91,7 +91,7 @@ def test_layer_geometry():
     assert E.LayerSpec('t', 128, 128, 3, 2).out_hw(8, 12) == (16, 24)
     assert E.LayerSpec('t', 128, 128, 5, 2).out_hw(8, 8) == (16, 16)
     assert E.LayerSpec('c', 64, 64, 3, 1, ups=1).out_hw(16, 16) == (32, 32)
-    assert E.cpad(1) == 4 and E.cpad(10) == 12 and E.cpad(128) == 128
+    assert E.cpad(1) == 8 and E.cpad(10) == 16 and E.cpad(128) == 128
     from master_thesis_amd.model_dfpn import FlowEstimator, _specs_from
     specs, params = _specs_from(FlowEstimator().nn)
     assert len(specs) == 21 and len(params) == 42
