@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvK p) {
 // Weights are split once at pack time; activations are split while they are
 // staged into LDS.  K per LDS stage: BKT = 32 (NS = 2) or 16 (NS = 3) so that
 // both fit two blocks per CU.
-template <int WGM, int WGN, int TM, int TN, int NS>
+template <int WGM, int WGN, int TM, int TN, int NS, bool PAR>
 __global__ __launch_bounds__(256) void igemm_split_kernel(ConvK p) {
   constexpr int BKT = NS == 3 ? 16 : 32;            // k per LDS stage
   constexpr int LD = BKT + 8;                       // bf16 per LDS row (+16 B pad: conflict-free b128 reads)
@@ -173,37 +173,69 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(ConvK p) {
   const int li = lane & 31, lh = lane >> 5;
   const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
 
+  // PAR: a stride-2 transposed gather (conv backward-data / conv_transpose
+  // forward) only touches taps with kh == (oy + pad) mod 2: instead of
+  // multiplying 3/4 zeros, blockIdx.z enumerates the four output-parity
+  // classes, each a dense stride-1 gather over its own tap subset
+  //   iy = yy + (py + pad - kh0)/2 - jh,   kh = kh0 + 2*jh.
+  PixMap pm = {p.Ho, p.Wo, p.M, 1, 0, 0};
+  int kh0 = 0, kw0 = 0, nkh = p.KH, nkw = p.KW, dyc = 0, dxc = 0;
+  if (PAR) {
+    pm.py = blockIdx.z >> 1; pm.px = blockIdx.z & 1; pm.ostep = 2;
+    pm.Hc = (p.Ho - pm.py + 1) >> 1; pm.Wc = (p.Wo - pm.px + 1) >> 1;
+    pm.M = p.N * pm.Hc * pm.Wc;
+    kh0 = (pm.py + p.pad) & 1; kw0 = (pm.px + p.pad) & 1;
+    nkh = (p.KH - kh0 + 1) >> 1; nkw = (p.KW - kw0 + 1) >> 1;
+    dyc = (pm.py + p.pad - kh0) >> 1; dxc = (pm.px + p.pad - kw0) >> 1;
+    if (m0 >= pm.M) return;
+  }
+  const int Kc = nkh * nkw * p.C;
+
   const int col4 = tid % FPR, row0 = tid / FPR;
   long a_off[RA];
   int a_oy[RA], a_ox[RA];
   bool a_ok[RA];
-  const int HWo = p.Ho * p.Wo;
+  const int HWo = pm.Hc * pm.Wc;
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     int m = m0 + row0 + RPP * i;
-    a_ok[i] = m < p.M;
+    a_ok[i] = m < pm.M;
     int mm = a_ok[i] ? m : 0;
     int n = mm / HWo;
     int r = mm - n * HWo;
-    a_oy[i] = r / p.Wo;
-    a_ox[i] = r - a_oy[i] * p.Wo;
+    a_oy[i] = r / pm.Wc;
+    a_ox[i] = r - a_oy[i] * pm.Wc;
     a_off[i] = (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
   }
   int kc = col4 * 4, kkh = 0, kkw = 0;
-  while (kc >= p.C) { kc -= p.C; if (++kkw == p.KW) { kkw = 0; ++kkh; } }
+  while (kc >= p.C) { kc -= p.C; if (++kkw == nkw) { kkw = 0; ++kkh; } }
   const int HL = p.H << p.ups, WL = p.W << p.ups;
   const int smask = p.stride - 1, sshift = p.stride >> 1;
   const __bf16* wt16 = reinterpret_cast<const __bf16*>(p.wt);
   const long plane = (long)p.Co * p.Kp;
+  // PAR: per-chunk (tap, channel) trackers for the weight tile, whose k' is a
+  // compacted enumeration of the class's taps
+  int bkc[RB], bjh[RB], bjw[RB];
+  if (PAR) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int w = (tid + 256 * i) % (BN * CPR);
+      bkc[i] = (w % CPR) * 8; bjh[i] = 0; bjw[i] = 0;
+      while (bkc[i] >= p.C) { bkc[i] -= p.C; if (++bjw[i] == nkw) { bjw[i] = 0; ++bjh[i]; } }
+    }
+  }
 
   f32x4 ra[RA];
   bf16x8 rb[RB];
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      bool ok = a_ok[i] && kkh < p.KH;
+      bool ok = a_ok[i] && kkh < nkh;
       int iy, ix;
-      if (!p.transposed) {
+      if (PAR) {
+        iy = a_oy[i] + dyc - kkh; ix = a_ox[i] + dxc - kkw;
+        ok = ok && (unsigned)iy < (unsigned)HL && (unsigned)ix < (unsigned)WL;
+      } else if (!p.transposed) {
         iy = a_oy[i] * p.stride - p.pad + kkh;
         ix = a_ox[i] * p.stride - p.pad + kkw;
         ok = ok && (unsigned)iy < (unsigned)HL && (unsigned)ix < (unsigned)WL;
@@ -225,12 +257,19 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(ConvK p) {
       bf16x8 v;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
-      if (c < NCH && n0 + row < p.Co)
+      if (PAR) {
+        if (c < NCH && n0 + row < p.Co && bjh[i] < nkh)
+          v = *reinterpret_cast<const bf16x8*>(wt16 + pl * plane + (long)(n0 + row) * p.Kp +
+                                               (long)((kh0 + 2 * bjh[i]) * p.KW + kw0 + 2 * bjw[i]) * p.C + bkc[i]);
+        bkc[i] += BKT;
+        while (bkc[i] >= p.C) { bkc[i] -= p.C; if (++bjw[i] == nkw) { bjw[i] = 0; ++bjh[i]; } }
+      } else if (c < NCH && n0 + row < p.Co) {
         v = *reinterpret_cast<const bf16x8*>(wt16 + pl * plane + (long)(n0 + row) * p.Kp + kt * BKT + ch * 8);
+      }
       rb[i] = v;
     }
     kc += BKT;
-    while (kc >= p.C) { kc -= p.C; if (++kkw == p.KW) { kkw = 0; ++kkh; } }
+    while (kc >= p.C) { kc -= p.C; if (++kkw == nkw) { kkw = 0; ++kkh; } }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
@@ -257,7 +296,7 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(ConvK p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int nk = (p.K + BKT - 1) / BKT;
+  const int nk = (Kc + BKT - 1) / BKT;
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -287,7 +326,7 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(ConvK p) {
     if (kt + 1 < nk) store_tile(buf ^ 1);
     __syncthreads();
   }
-  igemm_epilogue<TM, TN>(p, acc, m0, n0, wm, wn, li, lh);
+  igemm_epilogue_map<TM, TN>(p, pm, acc, m0, n0, wm, wn, li, lh);
 }
 
 // one thread per output element; the self-check restatement of the above
@@ -332,8 +371,15 @@ template <int WGM, int WGN, int TM, int TN>
 void launch_igemm(const ConvK& k, hipStream_t s, int prec = MT_PREC_F32) {
   constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
   dim3 grid((k.M + BM - 1) / BM, (k.Co + BN - 1) / BN, k.zb);
-  if (prec == MT_PREC_BF16X3) hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 2>), grid, dim3(256), 0, s, k);
-  else if (prec == MT_PREC_BF16X6) hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 3>), grid, dim3(256), 0, s, k);
+  if (k.par) {   // four output-parity classes of a stride-2 transposed gather
+    const int mc = k.N * ((k.Ho + 1) / 2) * ((k.Wo + 1) / 2);
+    dim3 g4((mc + BM - 1) / BM, (k.Co + BN - 1) / BN, 4);
+    if (prec == MT_PREC_BF16X3) hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 2, true>), g4, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 3, true>), g4, dim3(256), 0, s, k);
+    return;
+  }
+  if (prec == MT_PREC_BF16X3) hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 2, false>), grid, dim3(256), 0, s, k);
+  else if (prec == MT_PREC_BF16X6) hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 3, false>), grid, dim3(256), 0, s, k);
   else hipLaunchKernelGGL((igemm_kernel<WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
 }
 
@@ -746,6 +792,7 @@ extern "C" int mt_conv_run(const mt_conv* d, void* stream) {
   const int prec = d->precision;
   MT_REQUIRE(prec == MT_PREC_F32 || prec == MT_PREC_BF16X3 || prec == MT_PREC_BF16X6, "mt_conv: unknown precision %d", prec);
   if (prec != MT_PREC_F32) k.Kp = ((k.K + 31) / 32) * 32;
+  k.par = (prec != MT_PREC_F32 && k.transposed && k.stride == 2 && (k.C & 7) == 0 && k.ups == 0) ? 1 : 0;
   if (k.Co > 64) launch_igemm<2, 2, 2, 2>(k, s, prec);        // 128 x 128
   else if (k.Co > 32) launch_igemm<2, 2, 2, 1>(k, s, prec);   // 128 x 64
   else launch_igemm<4, 1, 1, 1>(k, s, prec);                  // 128 x 32

@@ -19,7 +19,8 @@ struct ConvK {
   const float* ds; long dsn, dsh, dsw; int dact, dact_c0;
   int accumulate;
   int zb, zdiv; long xz, wz, yz;   // batched GEMM over blockIdx.z (correlation)
-  int Kp;                          // bf16x3 path: padded row length of the packed weights
+  int Kp;                          // split paths: padded row length of the packed weights
+  int par;                         // 1: stride-2 transposed gather decomposed into 4 parity classes (blockIdx.z)
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give
@@ -32,10 +33,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nt) {
 }
 
 
+// Output-pixel enumeration of one launch: the plain case walks all Ho x Wo
+// pixels; a parity class (py, px) of a stride-2 transposed gather walks the
+// pixels (2*yy + py, 2*xx + px) only.
+struct PixMap { int Hc, Wc, M, ostep, py, px; };
+
 template <int TM, int TN>
-__device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                                               int li, int lh) {
-  const int HWo = p.Ho * p.Wo;
+__device__ __forceinline__ void igemm_epilogue_map(const ConvK& p, const PixMap& pm, f32x16 (&acc)[TM][TN], int m0,
+                                                   int n0, int wm, int wn, int li, int lh) {
+  const int HWo = pm.Hc * pm.Wc;
   // ---- epilogue -----------------------------------------------------------
   // C/D layout of the 32x32 tile: col (o) = lane & 31, row (pixel) =
   // (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -44,10 +50,11 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[TM]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (m >= p.M) continue;
+      if (m >= pm.M) continue;
       const int n = m / HWo;
       const int rem = m - n * HWo;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int yy = rem / pm.Wc, xx = rem - yy * pm.Wc;
+      const int oy = yy * pm.ostep + pm.py, ox = xx * pm.ostep + pm.px;
       const long yo = (long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + (long)oy * p.ysh + (long)ox * p.ysw;
       const long ro = p.res ? (long)n * p.rsn + (long)oy * p.rsh + (long)ox * p.rsw : 0;
       const long so = p.ds ? (long)n * p.dsn + (long)oy * p.dsh + (long)ox * p.dsw : 0;
@@ -65,6 +72,13 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[TM]
       }
     }
   }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
+                                               int li, int lh) {
+  const PixMap pm = {p.Ho, p.Wo, p.M, 1, 0, 0};
+  igemm_epilogue_map<TM, TN>(p, pm, acc, m0, n0, wm, wn, li, lh);
 }
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -138,7 +152,7 @@ inline int fill_convk(const mt_conv* d, ConvK* k) {
   k->res = d->res.p; k->rsn = d->res.sn; k->rsh = d->res.sh; k->rsw = d->res.sw; k->beta = d->beta;
   k->ds = d->dsrc.p; k->dsn = d->dsrc.sn; k->dsh = d->dsrc.sh; k->dsw = d->dsrc.sw; k->dact = d->dact; k->dact_c0 = d->dact_c0;
   k->accumulate = d->accumulate;
-  k->zb = 1; k->zdiv = 1; k->xz = k->wz = k->yz = 0;
+  k->zb = 1; k->zdiv = 1; k->xz = k->wz = k->yz = 0; k->par = 0; k->Kp = 0;
   return MT_OK;
 }
 

@@ -21,11 +21,15 @@ PROFILE = None            # list -> every conv-engine launch appends (kernel, fl
 #   'bf16x3'  2-term split, 3 partial products: ~4e-6 relative per layer
 #   'f32'     fp32-input MFMA
 PRECISION = os.environ.get('MT355_PRECISION', 'bf16x6')
-# convolutions that are never differentiated (the VGG feature passes, the DFPN
-# aligner inside the CHN step: torch.no_grad in the reference, model_dfpn.py:125,
-# 242,510, model_vgg.py:43) may run the cheaper 2-term split: ~4e-6 relative per
-# layer, far inside the 1e-3 output bar, and no gradient ever sees it
-PRECISION_NOGRAD = os.environ.get('MT355_PRECISION_NOGRAD', 'bf16x3')
+# The VGG feature passes are never differentiated (model_vgg.py:43 detaches, and
+# model_dfpn.py:242,510 run them under no_grad) and feed only smooth functions
+# (cosine correlation, L1 of features): they run the cheaper 2-term split
+# (~4e-6 relative per layer, far inside the 1e-3 output bar).  The DFPN aligner
+# inside the CHN step is also under no_grad, but its flow goes through a
+# NEAREST-neighbour warp of the visibility maps: extra rounding noise there
+# flips mask pixels, so it keeps the full precision unless asked otherwise.
+PRECISION_VGG = os.environ.get('MT355_PRECISION_VGG', 'bf16x3')
+PRECISION_NOGRAD = os.environ.get('MT355_PRECISION_NOGRAD', 'same')
 USE_HALO = os.environ.get('MT355_HALO', '1') != '0'   # LDS halo-tile kernel for stride-1 3x3/5x5 layers
 _PREC = {'f32': L.PREC_F32, 'bf16x3': L.PREC_BF16X3, 'bf16x6': L.PREC_BF16X6}
 _KTAG = {'f32': '', 'bf16x3': ',2', 'bf16x6': ',3'}
@@ -36,10 +40,16 @@ def _prec():
 
 
 def nograd_precision():
-    """Precision for a forward pass that keeps no autograd state."""
+    """Precision of conv stacks run under torch.no_grad (the aligner in CHN)."""
     if PRECISION == 'f32' or PRECISION_NOGRAD == 'same':
         return PRECISION
     return PRECISION_NOGRAD
+
+
+def vgg_precision():
+    if PRECISION == 'f32' or PRECISION_VGG == 'same':
+        return PRECISION
+    return PRECISION_VGG
 
 
 class precision:
@@ -327,11 +337,10 @@ class ConvStackFn(torch.autograd.Function):
     autograd node on NHWC4 tensors."""
 
     @staticmethod
-    def forward(ctx, x, specs, *params):
+    def forward(ctx, x, specs, keep, *params):
         assert x.is_contiguous() and x.dim() == 4
         acts = [x]
         cur = x
-        keep = any(ctx.needs_input_grad)
         with precision(PRECISION if keep else nograd_precision()):
             cur = ConvStackFn._run(specs, params, cur, acts)
         ctx.specs = specs
@@ -380,11 +389,17 @@ class ConvStackFn(torch.autograd.Function):
             conv_backward_data(sp, dz, w, yv, dsrc=xin if prev_act != L.ACT_NONE else None, dact=prev_act)
             dz = dx
             acts[i + 1] = None   # release the saved activation
-        return (dz, None) + tuple(grads)
+        return (dz, None, None) + tuple(grads)
+
+
+def will_differentiate(*tensors):
+    """True when autograd will record this call (Function.forward itself always
+    runs with grad mode off, and ctx.needs_input_grad ignores torch.no_grad)."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 def conv_stack(x, specs, params):
-    return ConvStackFn.apply(x, specs, *params)
+    return ConvStackFn.apply(x, specs, will_differentiate(x, *params), *params)
 
 
 # ------------------------------------------------------------ layout ops ---

@@ -35,8 +35,7 @@ class RRDBNetFn(torch.autograd.Function):
     """RRDBNet.forward (model_chn.py:538-555) and its backward on NHWC4."""
 
     @staticmethod
-    def forward(ctx, x4, net, names, *params):
-        keep = any(ctx.needs_input_grad)
+    def forward(ctx, x4, net, names, keep, *params):
         with E.precision(E.PRECISION if keep else E.nograd_precision()):
             out, saved = RRDBNetFn._run(x4, net, names, params, keep)
         ctx.saved, ctx.net, ctx.names = saved, net, names
@@ -171,7 +170,7 @@ class RRDBNetFn(torch.autograd.Function):
             if i > 0:
                 dz = bdata(f'conv_first.{i}', sp, dz, torch.empty_like(first[i]))
         ctx.saved = None
-        return (None, None, None) + tuple(G[nm] for nm in names)
+        return (None, None, None, None) + tuple(G[nm] for nm in names)
 
 
 class RRDBNet(nn.Module):
@@ -197,7 +196,7 @@ class RRDBNet(nn.Module):
     def forward4(self, x4):
         """NHWC4 in -> NHWC4 out."""
         names, params = zip(*self.named_parameters())
-        return RRDBNetFn.apply(x4, self, names, *params)
+        return RRDBNetFn.apply(x4, self, names, E.will_differentiate(x4, *params), *params)
 
     def forward(self, x):
         """(N,C,H,W) -> (N,out_nc,H,W), model_chn.py:538-555."""

@@ -44,7 +44,7 @@ class VGGFeatures(nn.Module):
         """NHWC4 in (N,H,W,4: already normalised) -> list of NHWC4 taps.  Stops
         after tap ``n_taps`` (DFPN only needs pool4, model_dfpn.py:516-518)."""
         taps, cur = [], x4
-        with E.precision(E.nograd_precision()):
+        with E.precision(E.vgg_precision()):
             return self._forward4(cur, n_taps)
 
     def _forward4(self, cur, n_taps):
