@@ -46,6 +46,11 @@ enum mt_precision { MT_PREC_F32 = 0, MT_PREC_BF16X3 = 1, MT_PREC_BF16X6 = 2 };
  * convolution for stride-1 3x3/5x5 "same" layers (split precisions, X.C % 8 ==
  * 0) and the implicit-GEMM gather kernel otherwise; IGEMM forces the latter. */
 enum mt_algo { MT_ALGO_AUTO = 0, MT_ALGO_IGEMM = 1 };
+/* Layout of mt_conv.wt: ROWS = [Cout_p][KH*KW][Cin_p] rows (mt_weight_pack /
+ * mt_weight_pack_split: every kernel but the halo one); HALO = the per-tile LDS
+ * images of mt_weight_pack_halo (required by, and only valid for, layers that
+ * MT_ALGO_AUTO sends to the halo-tile kernel). */
+enum mt_wt_layout { MT_WT_ROWS = 0, MT_WT_HALO = 1 };
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -102,6 +107,7 @@ typedef struct {
   int32_t accumulate;
   int32_t precision;  /* mt_precision; split precisions need wt from mt_weight_pack_split */
   int32_t algo;       /* mt_algo */
+  int32_t wt_layout;  /* mt_wt_layout */
 } mt_conv;
 
 int mt_conv_run(const mt_conv* d, void* stream);
@@ -156,6 +162,14 @@ int mt_weight_pack_split(const float* src, int32_t A, int32_t B, int32_t T,
                          int64_t sa, int64_t sb, int64_t st, void* dst,
                          int32_t AP, int32_t BP, int32_t precision, int32_t flip,
                          void* stream);
+/* Weight tiles of the halo-tile kernel: dst = [tap][chunk][ntile][plane][BN][CK+8]
+ * bf16, every tile the exact LDS image the kernel copies (CK = 32 / 16 input
+ * channels per chunk for BF16X3 / BF16X6, BN = 128 / 64 / 32 by AP). */
+int64_t mt_weight_pack_halo_elems(int32_t AP, int32_t BP, int32_t T, int32_t precision);
+int mt_weight_pack_halo(const float* src, int32_t A, int32_t B, int32_t T,
+                        int64_t sa, int64_t sb, int64_t st, void* dst,
+                        int32_t AP, int32_t BP, int32_t precision, int32_t flip,
+                        void* stream);
 int mt_pad_vector(const float* src, int32_t n, float* dst, int32_t np, void* stream);
 
 /* ---- layout / streaming kernels --------------------------------------- */

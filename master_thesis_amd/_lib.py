@@ -26,7 +26,7 @@ class Conv(C.Structure):
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('transposed', i32), ('ups', i32), ('act', i32), ('alpha', f32),
                 ('res', View), ('beta', f32), ('dsrc', View), ('dact', i32),
-                ('dact_c0', i32), ('accumulate', i32), ('precision', i32), ('algo', i32)]
+                ('dact_c0', i32), ('accumulate', i32), ('precision', i32), ('algo', i32), ('wt_layout', i32)]
 
 
 class Wgrad(C.Structure):
@@ -64,6 +64,8 @@ SIGNATURES = {
     'mt_bias_grad': [_P(View), _vp, i32, _vp, i32, _vp],
     'mt_weight_pack': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, _vp],
     'mt_weight_pack_split': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp],
+    'mt_weight_pack_halo': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp],
+    'mt_weight_pack_halo_elems': [i32, i32, i32, i32],
     'mt_pad_vector': [_vp, i32, _vp, i32, _vp],
     'mt_nchw_to_nhwc4': [_vp, i64, i64, i64, i64, i32, i32, i32, i32, _vp, _vp, _P(View), i32, _vp],
     'mt_nhwc4_to_nchw': [_P(View), i32, _vp, i64, i64, i64, i64, i32, _vp, _vp, i32, _vp],
@@ -85,7 +87,7 @@ SIGNATURES = {
     'mt_adam_step': [_vp, _vp, _vp, _vp, i64, f32, f32, f32, f32, f32, f32, _vp],
     'mt_adam_step_dev': [_vp, _vp, _vp, _vp, i64, f32, f32, f32, f32, _vp, _vp],
 }
-_RESTYPES = {'mt_last_error': C.c_char_p, 'mt_wgrad_slab_floats': i64}
+_RESTYPES = {'mt_last_error': C.c_char_p, 'mt_wgrad_slab_floats': i64, 'mt_weight_pack_halo_elems': i64}
 
 _lib = None
 

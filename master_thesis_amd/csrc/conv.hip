@@ -785,6 +785,7 @@ int mt_halo_try_launch(const mt_conv* d, void* stream);   // conv_halo.hip
 
 extern "C" int mt_conv_run(const mt_conv* d, void* stream) {
   if (d && d->algo == MT_ALGO_AUTO && mt_halo_try_launch(d, stream)) return mt_check_launch("mt_conv_run(halo)");
+  MT_REQUIRE(!d || d->wt_layout == MT_WT_ROWS, "mt_conv: halo weight tiles given to a layer the halo kernel does not take");
   ConvK k;
   int rc = fill_convk(d, &k);
   if (rc) return rc;

@@ -25,7 +25,6 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
   constexpr int BN = WGN * TN * 32;
   constexpr int HW_ = TW + KS - 1, HH = TH + KS - 1, HP = HH * HW_;   // halo patch
   constexpr int F4 = CK / 4, NH4 = HP * F4, RH = (NH4 + 255) / 256;
-  constexpr int CPR = CK / 8, NCH = NS * BN * CPR, RB = (NCH + 255) / 256;
   constexpr int T = KS * KS;
   __shared__ __attribute__((aligned(16))) __bf16 sH[NS][HP * LD];
   __shared__ __attribute__((aligned(16))) __bf16 sB[2][NS][BN * LD];
@@ -54,8 +53,13 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
     h_ok[i] = idx < NH4 && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL;
     h_off[i] = (long)(ly >> p.ups) * p.xsh + (long)(lx >> p.ups) * p.xsw + 4 * c4;
   }
+  // weights come as the exact LDS image of every (tap, chunk, n-tile) B tile:
+  // [tap][chunk][ntile][plane][BN rows][LD] bf16 (mt_weight_pack_halo), so a
+  // tile is one contiguous blob and every load instruction moves a full 1 KiB
   const __bf16* wt16 = reinterpret_cast<const __bf16*>(p.wt);
-  const long plane = (long)p.Co * p.Kp;
+  const int nchunk_w = (p.C + CK - 1) / CK, ntile_w = (p.Co + BN - 1) / BN;
+  constexpr int TILE_E = NS * BN * LD;              // bf16 elements per tile image
+  constexpr int NCH = TILE_E / 8, RB = (NCH + 255) / 256;
 
   f32x4 rh[RH];
   bf16x8 rb[RB];
@@ -81,27 +85,39 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
       }
     }
   };
-  auto load_B = [&](int c0, int tap) {
+#ifdef MT_HALO_REGSTAGE
+  auto load_B = [&](int c0, int tap, int buf) {
+    const __bf16* tile = wt16 + ((long)(tap * nchunk_w + c0 / CK) * ntile_w + blockIdx.y) * TILE_E;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int c = tid + 256 * i;
-      const int pl = c / (BN * CPR), w = c % (BN * CPR), row = w / CPR, ch = w % CPR;
-      bf16x8 v;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
-      if (c < NCH && n0 + row < p.Co && c0 + ch * 8 < p.C)
-        v = *reinterpret_cast<const bf16x8*>(wt16 + pl * plane + (long)(n0 + row) * p.Kp + (long)tap * p.C + c0 + ch * 8);
-      rb[i] = v;
+      if (c < NCH) rb[i] = *reinterpret_cast<const bf16x8*>(tile + c * 8);
     }
   };
   auto store_B = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int c = tid + 256 * i;
-      const int pl = c / (BN * CPR), w = c % (BN * CPR), row = w / CPR, ch = w % CPR;
-      if (c < NCH) *reinterpret_cast<bf16x8*>(&sB[buf][pl][row * LD + ch * 8]) = rb[i];
+      if (c < NCH) *reinterpret_cast<bf16x8*>(&sB[buf][0][c * 8]) = rb[i];
     }
   };
+#else
+  // LDS-DMA: the weight tile in HBM is the LDS image itself, so it is copied
+  // global -> LDS directly (wave-uniform LDS base + lane * 16 B), no VGPR round
+  // trip and no ds_write; __syncthreads() drains it before the tile is read
+  auto load_B = [&](int c0, int tap, int buf) {
+    const __bf16* tile = wt16 + ((long)(tap * nchunk_w + c0 / CK) * ntile_w + blockIdx.y) * TILE_E;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int c = tid + 256 * i;
+      if (c < NCH)
+        __builtin_amdgcn_global_load_lds((const unsigned*)(tile + c * 8),
+                                         (__attribute__((address_space(3))) unsigned*)(&sB[buf][0][(c - lane) * 8]),
+                                         16, 0, 0);
+    }
+  };
+  auto store_B = [&](int) {};
+#endif
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -125,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
   const int nchunk = (p.C + CK - 1) / CK;
   load_halo(0);
   store_halo();
-  load_B(0, 0);
+  load_B(0, 0, 0);
   store_B(0);
   __syncthreads();
   int it = 0;
@@ -137,8 +153,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
     for (int tap = 0; tap < T; ++tap, ++it) {
       const int buf = it & 1;
       const bool last = tap == T - 1;
-      if (!last) load_B(c0, tap + 1);
-      else if (more) load_B(c0 + CK, 0);
+      if (!last) load_B(c0, tap + 1, buf ^ 1);
+      else if (more) load_B(c0 + CK, 0, buf ^ 1);
       const int toff = (kh * HW_ + kw) * LD;
 #pragma unroll
       for (int ks = 0; ks < CK / 16; ++ks) {
@@ -216,7 +232,7 @@ void launch_halo(const ConvK& k, hipStream_t s) {
 int mt_halo_try_launch(const mt_conv* d, void* stream) {
   if (d->precision != MT_PREC_BF16X3 && d->precision != MT_PREC_BF16X6) return 0;
   if (d->transposed || d->stride != 1 || d->KH != d->KW || (d->KH != 3 && d->KH != 5) || d->pad != d->KH / 2) return 0;
-  if ((d->x.C & 7) != 0) return 0;
+  if ((d->x.C & 7) != 0 || d->wt_layout != MT_WT_HALO) return 0;
   ConvK k;
   if (fill_convk(d, &k) != MT_OK) return 0;
   k.Kp = ((k.K + 31) / 32) * 32;
@@ -441,4 +457,54 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
     else hipLaunchKernelGGL((wgrad_halo_kernel<5, MT_WG5_KHB, 2, MT_WG5_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
   }
   return 1;
+}
+
+namespace {
+// dst[tap][chunk][ntile][plane][BN][LD]: the LDS image of every weight tile of
+// igemm_halo_kernel (pad columns and out-of-range rows/channels are zero)
+__global__ void weight_pack_halo_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
+                                        int BN, int CK, int NS, int nchunk, int ntile, int flip) {
+  const int LD = CK + 8;
+  const long tile_e = (long)NS * BN * LD;
+  const long total = (long)T * nchunk * ntile * BN * LD;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(e % LD);
+    long r = e / LD;
+    const int row = (int)(r % BN); r /= BN;
+    const int nt = (int)(r % ntile); r /= ntile;
+    const int ch = (int)(r % nchunk);
+    const int t = (int)(r / nchunk);
+    const int a = nt * BN + row, b = ch * CK + col;
+    float v = 0.f;
+    if (col < CK && a < A && b < B) v = src[a * sa + b * sb + (flip ? T - 1 - t : t) * st];
+    __bf16* tile = dst + ((long)(t * nchunk + ch) * ntile + nt) * tile_e;
+    for (int s = 0; s < NS; ++s) {
+      const __bf16 h = (__bf16)v;
+      tile[((long)s * BN + row) * LD + col] = h;
+      v -= (float)h;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int64_t mt_weight_pack_halo_elems(int32_t AP, int32_t BP, int32_t T, int32_t precision) {
+  const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = NS == 3 ? 16 : 32, LD = CK + 8;
+  const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);
+  return (int64_t)T * ((BP + CK - 1) / CK) * ((AP + BN - 1) / BN) * NS * BN * LD;
+}
+
+extern "C" int mt_weight_pack_halo(const float* src, int32_t A, int32_t B, int32_t T, int64_t sa, int64_t sb,
+                                   int64_t st, void* dst, int32_t AP, int32_t BP, int32_t precision, int32_t flip,
+                                   void* stream) {
+  MT_REQUIRE(src && dst && A <= AP && B <= BP && (BP & 7) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
+             "mt_weight_pack_halo: bad arguments");
+  MT_REQUIRE(precision == MT_PREC_BF16X3 || precision == MT_PREC_BF16X6, "mt_weight_pack_halo: precision");
+  const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = NS == 3 ? 16 : 32;
+  const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);        // the n-tile igemm_halo uses for Co = AP
+  const int nchunk = (BP + CK - 1) / CK, ntile = (AP + BN - 1) / BN;
+  const long total = (long)T * nchunk * ntile * BN * (CK + 8);
+  hipLaunchKernelGGL(weight_pack_halo_kernel, dim3(mt_grid_1d(total, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, A, B, T, (long)sa, (long)sb, (long)st,
+                     reinterpret_cast<__bf16*>(dst), BN, CK, NS, nchunk, ntile, flip);
+  return mt_check_launch("mt_weight_pack_halo");
 }

@@ -68,6 +68,12 @@ class precision:
         PRECISION = self.old
 
 
+def halo_eligible(kind_fwd_like, stride, k, cin_p):
+    """Mirror of mt_halo_try_launch: non-transposed stride-1 3x3/5x5 'same'
+    layers on a split precision with >= 8-aligned input channels."""
+    return USE_HALO and PRECISION != 'f32' and kind_fwd_like and stride == 1 and k in (3, 5) and cin_p % 8 == 0
+
+
 def _igemm_name(co, d=None):
     cfg = '2,2,2,2' if co > 64 else ('2,2,2,1' if co > 32 else '4,1,1,1')
     if d is not None and PRECISION != 'f32' and d.algo == 0 and not d.transposed and d.stride == 1 \
@@ -134,10 +140,10 @@ def null_view():
 
 
 # ------------------------------------------------------------ weight packs --
-def _pack(w, a_dim, kind, flip=False):
+def _pack(w, a_dim, kind, flip=False, halo=False):
     """[AP][T][BP] packed copy of a conv weight.  ``a_dim`` selects which of
     the two leading dims of ``w`` becomes the GEMM's output-channel axis."""
-    key = (w.data_ptr(), w._version, kind, PRECISION, WEIGHT_EPOCH)
+    key = (w.data_ptr(), w._version, kind, halo, PRECISION, WEIGHT_EPOCH)
     hit = _pack_cache.get(key)
     if hit is not None:
         return hit[0]
@@ -148,7 +154,12 @@ def _pack(w, a_dim, kind, flip=False):
         a, b, sa, sb = d0, d1, d1 * t, t
     else:
         a, b, sa, sb = d1, d0, t, d1 * t
-    if PRECISION != 'f32':
+    if halo:
+        n = L.load().mt_weight_pack_halo_elems(cpad(a), cpad(b), t, _prec())
+        out = torch.empty((n,), device=w.device, dtype=torch.bfloat16)
+        L.call('mt_weight_pack_halo', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _prec(),
+               1 if flip else 0, L.stream_ptr())
+    elif PRECISION != 'f32':
         kp = (t * cpad(b) + 31) // 32 * 32
         out = torch.empty((3 if PRECISION == 'bf16x6' else 2, cpad(a), kp), device=w.device, dtype=torch.bfloat16)
         L.call('mt_weight_pack_split', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _prec(),
@@ -203,7 +214,9 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
         out = torch.empty((n, ho, wo, cpad(spec.cout)), device=w.device, dtype=torch.float32)
     d = L.Conv()
     d.x, d.y = xv, view_of(out)
-    d.wt = _pack(w, 0 if spec.kind == 'c' else 1, 'f').data_ptr()
+    halo = halo_eligible(spec.kind == 'c', spec.stride, spec.k, xv.C)
+    d.wt = _pack(w, 0 if spec.kind == 'c' else 1, 'f', halo=halo).data_ptr()
+    d.wt_layout = 1 if halo else 0
     pb = _pad_bias(b, spec.cout)
     d.bias = pb.data_ptr() if pb is not None else None
     d.KH = d.KW = spec.k
@@ -233,8 +246,9 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     # the backward-data of a stride-1 "same" Conv2d is itself a stride-1 "same"
     # convolution with tap-flipped, channel-swapped weights: run it as a forward
     # conv so that it takes the halo-tile kernel
-    as_fwd = USE_HALO and spec.kind == 'c' and spec.stride == 1 and PRECISION != 'f32' and dz.shape[3] % 8 == 0
-    d.wt = _pack(w, 1 if spec.kind == 'c' else 0, 'bflip' if as_fwd else 'b', flip=as_fwd).data_ptr()
+    as_fwd = halo_eligible(spec.kind == 'c', spec.stride, spec.k, dz.shape[3])
+    d.wt = _pack(w, 1 if spec.kind == 'c' else 0, 'bflip' if as_fwd else 'b', flip=as_fwd, halo=as_fwd).data_ptr()
+    d.wt_layout = 1 if as_fwd else 0
     d.bias = None
     d.KH = d.KW = spec.k
     d.stride, d.pad, d.ups = spec.stride, spec.pad, 0
