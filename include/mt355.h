@@ -40,8 +40,14 @@ enum mt_act { MT_ACT_NONE = 0, MT_ACT_RELU = 1, MT_ACT_LRELU02 = 2 };
  *                on v_mfma_f32_32x32x16_bf16, fp32 accumulate: 17-18 significant
  *                bits (~4e-6 relative per layer), 5.3x the fp32-MFMA rate;
  * MT_PREC_BF16X6 3 bf16 terms, 6 partial products: >= 24 significant bits =
- *                fp32-equivalent, 2.7x the fp32-MFMA rate. */
-enum mt_precision { MT_PREC_F32 = 0, MT_PREC_BF16X3 = 1, MT_PREC_BF16X6 = 2 };
+ *                fp32-equivalent, 2.7x the fp32-MFMA rate;
+ * MT_PREC_F16X3  2 fp16 terms (22 significant bits) of the operand scaled by a
+ *                per-tensor power of two, 3 partial products on
+ *                v_mfma_f32_32x32x16_f16: ~7e-8 relative per product (below the
+ *                fp32 accumulation noise) at the BF16X3 cost.  Halo-tile
+ *                kernels only; needs the device scalars max|X|, max|W| (or
+ *                max|D|, max|G|) from mt_absmax. */
+enum mt_precision { MT_PREC_F32 = 0, MT_PREC_BF16X3 = 1, MT_PREC_BF16X6 = 2, MT_PREC_F16X3 = 3 };
 /* Kernel selection of mt_conv_run: AUTO picks the LDS halo-tile direct
  * convolution for stride-1 3x3/5x5 "same" layers (split precisions, X.C % 8 ==
  * 0) and the implicit-GEMM gather kernel otherwise; IGEMM forces the latter. */
@@ -108,6 +114,8 @@ typedef struct {
   int32_t precision;  /* mt_precision; split precisions need wt from mt_weight_pack_split */
   int32_t algo;       /* mt_algo */
   int32_t wt_layout;  /* mt_wt_layout */
+  const float* x_amax; /* MT_PREC_F16X3: device scalar >= max|X| (mt_absmax) */
+  const float* w_amax; /* MT_PREC_F16X3: the scalar given to mt_weight_pack_halo */
 } mt_conv;
 
 int mt_conv_run(const mt_conv* d, void* stream);
@@ -132,6 +140,8 @@ typedef struct {
   int32_t with_bias;  /* halo-tile path only: also sum D over the pixels (the
                          bias gradient when D = dY); the slabs then carry
                          KH*KW + 1 taps, tap KH*KW / column 0 = those sums */
+  const float* d_amax; /* MT_PREC_F16X3: device scalars >= max|D|, max|G| */
+  const float* g_amax;
 } mt_wgrad;
 
 int mt_wgrad_run(const mt_wgrad* d, void* stream);
@@ -169,7 +179,11 @@ int64_t mt_weight_pack_halo_elems(int32_t AP, int32_t BP, int32_t T, int32_t pre
 int mt_weight_pack_halo(const float* src, int32_t A, int32_t B, int32_t T,
                         int64_t sa, int64_t sb, int64_t st, void* dst,
                         int32_t AP, int32_t BP, int32_t precision, int32_t flip,
-                        void* stream);
+                        const float* w_amax, void* stream);
+/* out[0] = max(out[0], max |x|) over an NHWC4 view / a flat array (atomic max on
+ * the device scalar: zero it first; several calls may share one scalar). */
+int mt_absmax(const mt_view* x, float* out, void* stream);
+int mt_absmax_flat(const float* p, int64_t n, float* out, void* stream);
 int mt_pad_vector(const float* src, int32_t n, float* dst, int32_t np, void* stream);
 
 /* ---- layout / streaming kernels --------------------------------------- */

@@ -26,13 +26,15 @@ class Conv(C.Structure):
                 ('KH', i32), ('KW', i32), ('stride', i32), ('pad', i32),
                 ('transposed', i32), ('ups', i32), ('act', i32), ('alpha', f32),
                 ('res', View), ('beta', f32), ('dsrc', View), ('dact', i32),
-                ('dact_c0', i32), ('accumulate', i32), ('precision', i32), ('algo', i32), ('wt_layout', i32)]
+                ('dact_c0', i32), ('accumulate', i32), ('precision', i32), ('algo', i32), ('wt_layout', i32),
+                ('x_amax', C.c_void_p), ('w_amax', C.c_void_p)]
 
 
 class Wgrad(C.Structure):
     _fields_ = [('d', View), ('g', View), ('KH', i32), ('KW', i32),
                 ('stride', i32), ('pad', i32), ('ups', i32), ('splits', i32),
-                ('slabs', C.c_void_p), ('precision', i32), ('algo', i32), ('with_bias', i32)]
+                ('slabs', C.c_void_p), ('precision', i32), ('algo', i32), ('with_bias', i32),
+                ('d_amax', C.c_void_p), ('g_amax', C.c_void_p)]
 
 
 class WarpLayout(C.Structure):
@@ -48,7 +50,7 @@ class PackSrc(C.Structure):
 
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
-PREC_F32, PREC_BF16X3, PREC_BF16X6 = 0, 1, 2
+PREC_F32, PREC_BF16X3, PREC_BF16X6, PREC_F16X3 = 0, 1, 2, 3
 _P = C.POINTER
 _vp = C.c_void_p
 
@@ -64,7 +66,9 @@ SIGNATURES = {
     'mt_bias_grad': [_P(View), _vp, i32, _vp, i32, _vp],
     'mt_weight_pack': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, _vp],
     'mt_weight_pack_split': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp],
-    'mt_weight_pack_halo': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp],
+    'mt_weight_pack_halo': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp, _vp],
+    'mt_absmax': [_P(View), _vp, _vp],
+    'mt_absmax_flat': [_vp, i64, _vp, _vp],
     'mt_weight_pack_halo_elems': [i32, i32, i32, i32],
     'mt_pad_vector': [_vp, i32, _vp, i32, _vp],
     'mt_nchw_to_nhwc4': [_vp, i64, i64, i64, i64, i32, i32, i32, i32, _vp, _vp, _P(View), i32, _vp],

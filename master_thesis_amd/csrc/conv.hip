@@ -791,7 +791,8 @@ extern "C" int mt_conv_run(const mt_conv* d, void* stream) {
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int prec = d->precision;
-  MT_REQUIRE(prec == MT_PREC_F32 || prec == MT_PREC_BF16X3 || prec == MT_PREC_BF16X6, "mt_conv: unknown precision %d", prec);
+  MT_REQUIRE(prec == MT_PREC_F32 || prec == MT_PREC_BF16X3 || prec == MT_PREC_BF16X6,
+             "mt_conv: precision %d is not available on the implicit-GEMM kernels (F16X3 is halo-tile only)", prec);
   if (prec != MT_PREC_F32) k.Kp = ((k.K + 31) / 32) * 32;
   k.par = (prec != MT_PREC_F32 && k.transposed && k.stride == 2 && (k.C & 7) == 0 && k.ups == 0) ? 1 : 0;
   if (k.Co > 64) launch_igemm<2, 2, 2, 2>(k, s, prec);        // 128 x 128
@@ -841,7 +842,8 @@ extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
   wgrad_cfg(d, &k.atiles, &k.btiles, &cfg);
   dim3 grid(k.atiles * k.btiles * d->KH * d->KW, d->splits);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  MT_REQUIRE(d->precision >= MT_PREC_F32 && d->precision <= MT_PREC_BF16X6, "mt_wgrad: unknown precision");
+  MT_REQUIRE(d->precision >= MT_PREC_F32 && d->precision <= MT_PREC_BF16X6,
+             "mt_wgrad: precision not available on the generic kernel (F16X3 is halo-tile only)");
 #define MT_WG_LAUNCH(KERN, ...)                                                                         \
   switch (cfg) {                                                                                        \
     case 0: hipLaunchKernelGGL((KERN<2, 2, 2, 2 __VA_ARGS__>), grid, dim3(256), 0, s, k); break;        \

@@ -21,6 +21,7 @@ struct ConvK {
   int zb, zdiv; long xz, wz, yz;   // batched GEMM over blockIdx.z (correlation)
   int Kp;                          // split paths: padded row length of the packed weights
   int par;                         // 1: stride-2 transposed gather decomposed into 4 parity classes (blockIdx.z)
+  const float* xamax; const float* wamax;   // F16X3: device scalars max|X|, max|W| (power-of-two scaling)
 };
 
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give
@@ -112,6 +113,56 @@ __device__ __forceinline__ void mfma_split(const bf16x8 (&a)[NS], const bf16x8 (
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
 }
 
+// ---- split-fp16 with per-tensor power-of-two scaling ("f16x3") -------------
+// fp16 carries 11 significant bits, so TWO terms (hi = fp16(a*s), lo =
+// fp16(a*s - hi)) hold 22 bits and three partial products (lo*hi, hi*lo, hi*hi)
+// reproduce the fp32 product to ~7e-8 relative -- below the fp32 accumulation
+// noise -- at HALF the MFMA work of bf16x6.  fp16's narrow exponent range is
+// handled by one power-of-two scale per tensor, s = 2^(14 - e) with max|a| =
+// m * 2^e: the scaled tensor tops out in [2^13, 2^14), elements more than ~2^27
+// below the maximum degrade gracefully towards fixed point.  max|a| comes from
+// mt_absmax (a device scalar: nothing syncs with the host).
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float pow2_scale(float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+  int e;
+  (void)frexpf(amax, &e);
+  int k = 14 - e;
+  k = k > 126 ? 126 : (k < -126 ? -126 : k);
+  return ldexpf(1.f, k);
+}
+
+template <int NS, int FMT>
+__device__ __forceinline__ void split4f(const f32x4& v, float scale, bf16x4 (&out)[NS]) {
+  if constexpr (FMT == 0) {
+    split4<NS>(v, out);
+  } else {
+    static_assert(NS == 2, "f16x3 uses two fp16 terms");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float r = v[j] * scale;
+      const _Float16 h = (_Float16)r;
+      const _Float16 l = (_Float16)(r - (float)h);
+      out[0][j] = __builtin_bit_cast(__bf16, h);
+      out[1][j] = __builtin_bit_cast(__bf16, l);
+    }
+  }
+}
+
+template <int NS, int FMT>
+__device__ __forceinline__ void mfma_splitf(const bf16x8 (&a)[NS], const bf16x8 (&b)[NS], f32x16& acc) {
+  if constexpr (FMT == 0) {
+    mfma_split<NS>(a, b, acc);
+  } else {
+    const half8 a0 = __builtin_bit_cast(half8, a[0]), a1 = __builtin_bit_cast(half8, a[1]);
+    const half8 b0 = __builtin_bit_cast(half8, b[0]), b1 = __builtin_bit_cast(half8, b[1]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
+  }
+}
+
 struct WgK {
   const float* d; long dsn, dsh, dsw; int Hd, Wd, Cd;
   const float* g; long gsn, gsh, gsw; int Hg, Wg, Cg;
@@ -120,6 +171,7 @@ struct WgK {
   int M, per_split;   // pixels, pixels per split (multiple of 32)
   int atiles, btiles;
   float* slabs;
+  const float* damax; const float* gamax;   // F16X3: device scalars max|D|, max|G|
 };
 
 inline int fill_convk(const mt_conv* d, ConvK* k) {
@@ -153,6 +205,7 @@ inline int fill_convk(const mt_conv* d, ConvK* k) {
   k->ds = d->dsrc.p; k->dsn = d->dsrc.sn; k->dsh = d->dsrc.sh; k->dsw = d->dsrc.sw; k->dact = d->dact; k->dact_c0 = d->dact_c0;
   k->accumulate = d->accumulate;
   k->zb = 1; k->zdiv = 1; k->xz = k->wz = k->yz = 0; k->par = 0; k->Kp = 0;
+  k->xamax = d->x_amax; k->wamax = d->w_amax;
   return MT_OK;
 }
 

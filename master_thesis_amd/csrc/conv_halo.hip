@@ -16,7 +16,7 @@
 
 namespace {
 
-template <int KS, int NS, int WGM, int WGN, int TM, int TN>
+template <int KS, int NS, int FMT, int WGM, int WGN, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y, int tiles_x) {
   constexpr int CK = NS == 3 ? 16 : 32;             // input channels per LDS stage
   constexpr int LD = CK + 8;                        // bf16 per LDS row (+16 B pad)
@@ -39,6 +39,9 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
   const int n = bid / tiles_y;
   const int ty0 = ty * TH, tx0 = tx * TW, n0 = blockIdx.y * BN;
   const int HL = p.H << p.ups, WL = p.W << p.ups;
+  // F16X3: per-tensor power-of-two scales of the activations and the weights
+  const float sA = FMT ? pow2_scale(*p.xamax) : 1.f;
+  const float inv = FMT ? 1.f / (sA * pow2_scale(*p.wamax)) : 1.f;
   const float* xin = p.x + (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
 
   // ---- halo staging coordinates (chunk-invariant) --------------------------
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
       if (idx < NH4) {
         const int hp = idx / F4, c4 = idx % F4;
         bf16x4 parts[NS];
-        split4<NS>(rh[i], parts);
+        split4f<NS, FMT>(rh[i], sA, parts);
 #pragma unroll
         for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sH[s][hp * LD + 4 * c4]) = parts[s];
       }
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
-          for (int b = 0; b < TN; ++b) mfma_split<NS>(fa[a], fb[b], acc[a][b]);
+          for (int b = 0; b < TN; ++b) mfma_splitf<NS, FMT>(fa[a], fb[b], acc[a][b]);
       }
       if (!last || more) store_B(buf ^ 1);
       if (last && more) {
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
       for (int b = 0; b < TN; ++b) {
         const int o = n0 + wn * TN * 32 + b * 32 + li;
         if (o >= p.Co) continue;
-        float v = acc[a][b][r];
+        float v = acc[a][b][r] * inv;
         if (p.bias) v += p.bias[o];
         v = mt_act_fn(v, p.act) * p.alpha;
         if (p.res) v += p.beta * p.res[ro + o];
@@ -212,17 +215,17 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
   }
 }
 
-template <int KS, int NS>
+template <int KS, int NS, int FMT>
 void launch_halo(const ConvK& k, hipStream_t s) {
   const int tiles_y = (k.Ho + 7) / 8, tiles_x = (k.Wo + 15) / 16;
   const unsigned nt = (unsigned)k.N * tiles_y * tiles_x;
   if (k.Co > 64) {
-    hipLaunchKernelGGL((igemm_halo_kernel<KS, NS, 2, 2, 2, 2>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k,
+    hipLaunchKernelGGL((igemm_halo_kernel<KS, NS, FMT, 2, 2, 2, 2>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k,
                        tiles_y, tiles_x);
   } else if (k.Co > 32) {
-    hipLaunchKernelGGL((igemm_halo_kernel<KS, NS, 2, 2, 2, 1>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+    hipLaunchKernelGGL((igemm_halo_kernel<KS, NS, FMT, 2, 2, 2, 1>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
   } else {
-    hipLaunchKernelGGL((igemm_halo_kernel<KS, NS, 4, 1, 1, 1>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+    hipLaunchKernelGGL((igemm_halo_kernel<KS, NS, FMT, 4, 1, 1, 1>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
   }
 }
 
@@ -230,16 +233,24 @@ void launch_halo(const ConvK& k, hipStream_t s) {
 
 // Called by mt_conv_run: returns 1 if the launch was taken by the halo kernel.
 int mt_halo_try_launch(const mt_conv* d, void* stream) {
-  if (d->precision != MT_PREC_BF16X3 && d->precision != MT_PREC_BF16X6) return 0;
+  const int prec = d->precision;
+  if (prec != MT_PREC_BF16X3 && prec != MT_PREC_BF16X6 && prec != MT_PREC_F16X3) return 0;
   if (d->transposed || d->stride != 1 || d->KH != d->KW || (d->KH != 3 && d->KH != 5) || d->pad != d->KH / 2) return 0;
   if ((d->x.C & 7) != 0 || d->wt_layout != MT_WT_HALO) return 0;
+  if (prec == MT_PREC_F16X3 && (!d->x_amax || !d->w_amax)) return 0;
   ConvK k;
   if (fill_convk(d, &k) != MT_OK) return 0;
   k.Kp = ((k.K + 31) / 32) * 32;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool x6 = d->precision == MT_PREC_BF16X6;
-  if (d->KH == 3) { if (x6) launch_halo<3, 3>(k, s); else launch_halo<3, 2>(k, s); }
-  else { if (x6) launch_halo<5, 3>(k, s); else launch_halo<5, 2>(k, s); }
+  if (d->KH == 3) {
+    if (prec == MT_PREC_BF16X6) launch_halo<3, 3, 0>(k, s);
+    else if (prec == MT_PREC_BF16X3) launch_halo<3, 2, 0>(k, s);
+    else launch_halo<3, 2, 1>(k, s);
+  } else {
+    if (prec == MT_PREC_BF16X6) launch_halo<5, 3, 0>(k, s);
+    else if (prec == MT_PREC_BF16X3) launch_halo<5, 2, 0>(k, s);
+    else launch_halo<5, 2, 1>(k, s);
+  }
   return 1;
 }
 
@@ -264,7 +275,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int off, int ld) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int KS, int KHB, int NS, int OCC>
+template <int KS, int KHB, int NS, int FMT, int OCC>
 __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split,
                                                             int ntiles, int with_bias) {
   constexpr int TR = 4, TW = 16, PX = TR * TW;           // pixel tile: 4 rows x 16
@@ -286,6 +297,8 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
   const int split = blockIdx.y;
   const int t_beg = split * tiles_per_split, t_end = min(ntiles, t_beg + tiles_per_split);
   const int HL = p.Hg << p.ups, WL = p.Wg << p.ups;
+  const float scD = FMT ? pow2_scale(*p.damax) : 1.f, scG = FMT ? pow2_scale(*p.gamax) : 1.f;
+  const float inv = 1.f / (scD * scG), inv_d = 1.f / scD;
 
   // staging coordinates relative to the tile origin
   int d_ry[RD], d_rx[RD], d_c[RD];
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
 #pragma unroll
     for (int i = 0; i < RD; ++i) {
       bf16x4 parts[NS];
-      split4<NS>(rd[i], parts);
+      split4f<NS, FMT>(rd[i], scD, parts);
       const int px = (tid + 256 * i) / (CH / 4);
 #pragma unroll
       for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sD[s][px * LD + d_c[i]]) = parts[s];
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
     for (int i = 0; i < RG; ++i) {
       if (tid + 256 * i < NG4) {
         bf16x4 parts[NS];
-        split4<NS>(rg[i], parts);
+        split4f<NS, FMT>(rg[i], scG, parts);
         const int gp = (tid + 256 * i) / (CH / 4);
 #pragma unroll
         for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sG[s][gp * LD + g_c[i]]) = parts[s];
@@ -358,7 +371,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
   for (int r = 0; r < 16; ++r) acc_bias[r] = 0.f;
   bf16x8 ones;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+  for (int j = 0; j < 8; ++j) ones[j] = FMT ? __builtin_bit_cast(__bf16, (_Float16)1.0f) : (__bf16)1.0f;
 
   // transposed-read lane coordinates: 16-lane group g = lane >> 4 covers columns
   // 16*(g&1).., k rows 8*(g>>1) + q (+4); lane 4q+p supplies row q, columns 4p..
@@ -379,7 +392,10 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
       for (int s = 0; s < NS; ++s) fa[s] = tr_frag(sD[s], a_off + ks * 16 * LD, LD);
       if (do_bias) {
 #pragma unroll
-        for (int s = NS - 1; s >= 0; --s) acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], ones, acc_bias, 0, 0, 0);
+        for (int s = NS - 1; s >= 0; --s) {
+          if constexpr (FMT == 0) acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], ones, acc_bias, 0, 0, 0);
+          else acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[s]), __builtin_bit_cast(half8, ones), acc_bias, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int kh = 0; kh < KHB; ++kh)
@@ -388,7 +404,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
           bf16x8 fb[NS];
 #pragma unroll
           for (int s = 0; s < NS; ++s) fb[s] = tr_frag(sG[s], b_off + ((ks + kh) * GW + kw) * LD, LD);
-          mfma_split<NS>(fa, fb, acc[kh * KS + kw]);
+          mfma_splitf<NS, FMT>(fa, fb, acc[kh * KS + kw]);
         }
     }
   }
@@ -400,7 +416,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (ai < p.Cd) slab[((long)ai * TS + T) * p.Cg] = acc_bias[r];
+      if (ai < p.Cd) slab[((long)ai * TS + T) * p.Cg] = acc_bias[r] * inv_d;
     }
   }
 #pragma unroll
@@ -410,7 +426,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
     for (int r = 0; r < 16; ++r) {
       const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const int bi = b0 + wn * 32 + li;
-      if (ai < p.Cd && bi < p.Cg) slab[((long)ai * TS + tap) * p.Cg + bi] = acc[t][r];
+      if (ai < p.Cd && bi < p.Cg) slab[((long)ai * TS + tap) * p.Cg + bi] = acc[t][r] * inv;
     }
   }
 }
@@ -420,8 +436,10 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
 // Called by mt_wgrad_run: returns 1 if the launch was taken by the halo kernel.
 // `splits` blocks along y each own a contiguous range of pixel tiles.
 int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
-  if (d->precision != MT_PREC_BF16X3 && d->precision != MT_PREC_BF16X6) return 0;
+  const int prec = d->precision;
+  if (prec != MT_PREC_BF16X3 && prec != MT_PREC_BF16X6 && prec != MT_PREC_F16X3) return 0;
   if (d->stride != 1 || d->KH != d->KW || (d->KH != 3 && d->KH != 5) || d->pad != d->KH / 2) return 0;
+  if (prec == MT_PREC_F16X3 && (!d->d_amax || !d->g_amax)) return 0;
   WgK k;
   k.d = d->d.p; k.dsn = d->d.sn; k.dsh = d->d.sh; k.dsw = d->d.sw; k.Hd = d->d.H; k.Wd = d->d.W; k.Cd = d->d.C;
   k.g = d->g.p; k.gsn = d->g.sn; k.gsh = d->g.sh; k.gsw = d->g.sw; k.Hg = d->g.H; k.Wg = d->g.W; k.Cg = d->g.C;
@@ -430,32 +448,25 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   k.M = d->d.N * d->d.H * d->d.W; k.per_split = 0;
   k.atiles = (k.Cd + 63) / 64; k.btiles = (k.Cg + 63) / 64;
   k.slabs = d->slabs;
+  k.damax = d->d_amax; k.gamax = d->g_amax;
   const int tiles_y = (k.Hd + 3) / 4, tiles_x = (k.Wd + 15) / 16;
   const int ntiles = d->d.N * tiles_y * tiles_x;
   const int tps = (ntiles + d->splits - 1) / d->splits;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool x6 = d->precision == MT_PREC_BF16X6;
-#ifndef MT_WG3_KHB
-#define MT_WG3_KHB 3
-#endif
-#ifndef MT_WG3_OCC
-#define MT_WG3_OCC 1
-#endif
-  if (d->KH == 3) {
-    dim3 grid(k.atiles * k.btiles * (3 / MT_WG3_KHB), d->splits);
-    if (x6) hipLaunchKernelGGL((wgrad_halo_kernel<3, MT_WG3_KHB, 3, MT_WG3_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<3, MT_WG3_KHB, 2, MT_WG3_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
-  } else {
-#ifndef MT_WG5_KHB
-#define MT_WG5_KHB 1
-#endif
-#ifndef MT_WG5_OCC
-#define MT_WG5_OCC 2
-#endif
-    dim3 grid(k.atiles * k.btiles * (5 / MT_WG5_KHB), d->splits);
-    if (x6) hipLaunchKernelGGL((wgrad_halo_kernel<5, MT_WG5_KHB, 3, MT_WG5_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
-    else hipLaunchKernelGGL((wgrad_halo_kernel<5, MT_WG5_KHB, 2, MT_WG5_OCC>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
+#define MT_WGH(KS, KHB, NS, FMT, OCC, GRID) \
+  hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, NS, FMT, OCC>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias)
+  if (d->KH == 3) {   // all nine taps per block, one block per CU (the 9 accumulator tiles need the registers)
+    dim3 grid(k.atiles * k.btiles, d->splits);
+    if (prec == MT_PREC_BF16X6) MT_WGH(3, 3, 3, 0, 1, grid);
+    else if (prec == MT_PREC_BF16X3) MT_WGH(3, 3, 2, 0, 1, grid);
+    else MT_WGH(3, 3, 2, 1, 1, grid);
+  } else {            // one kernel row (5 taps) per block
+    dim3 grid(k.atiles * k.btiles * 5, d->splits);
+    if (prec == MT_PREC_BF16X6) MT_WGH(5, 1, 3, 0, 2, grid);
+    else if (prec == MT_PREC_BF16X3) MT_WGH(5, 1, 2, 0, 2, grid);
+    else MT_WGH(5, 1, 2, 1, 2, grid);
   }
+#undef MT_WGH
   return 1;
 }
 
@@ -463,7 +474,8 @@ namespace {
 // dst[tap][chunk][ntile][plane][BN][LD]: the LDS image of every weight tile of
 // igemm_halo_kernel (pad columns and out-of-range rows/channels are zero)
 __global__ void weight_pack_halo_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
-                                        int BN, int CK, int NS, int nchunk, int ntile, int flip) {
+                                        int BN, int CK, int NS, int nchunk, int ntile, int flip, const float* wamax) {
+  const float sc = wamax ? pow2_scale(*wamax) : 1.f;    // F16X3: fp16 planes of W * 2^k
   const int LD = CK + 8;
   const long tile_e = (long)NS * BN * LD;
   const long total = (long)T * nchunk * ntile * BN * LD;
@@ -478,10 +490,17 @@ __global__ void weight_pack_halo_kernel(const float* src, int A, int B, int T, l
     float v = 0.f;
     if (col < CK && a < A && b < B) v = src[a * sa + b * sb + (flip ? T - 1 - t : t) * st];
     __bf16* tile = dst + ((long)(t * nchunk + ch) * ntile + nt) * tile_e;
-    for (int s = 0; s < NS; ++s) {
-      const __bf16 h = (__bf16)v;
-      tile[((long)s * BN + row) * LD + col] = h;
-      v -= (float)h;
+    if (wamax) {
+      v *= sc;
+      const _Float16 h = (_Float16)v;
+      tile[((long)0 * BN + row) * LD + col] = __builtin_bit_cast(__bf16, h);
+      tile[((long)1 * BN + row) * LD + col] = __builtin_bit_cast(__bf16, (_Float16)(v - (float)h));
+    } else {
+      for (int s = 0; s < NS; ++s) {
+        const __bf16 h = (__bf16)v;
+        tile[((long)s * BN + row) * LD + col] = h;
+        v -= (float)h;
+      }
     }
   }
 }
@@ -495,16 +514,18 @@ extern "C" int64_t mt_weight_pack_halo_elems(int32_t AP, int32_t BP, int32_t T, 
 
 extern "C" int mt_weight_pack_halo(const float* src, int32_t A, int32_t B, int32_t T, int64_t sa, int64_t sb,
                                    int64_t st, void* dst, int32_t AP, int32_t BP, int32_t precision, int32_t flip,
-                                   void* stream) {
+                                   const float* w_amax, void* stream) {
   MT_REQUIRE(src && dst && A <= AP && B <= BP && (BP & 7) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
              "mt_weight_pack_halo: bad arguments");
-  MT_REQUIRE(precision == MT_PREC_BF16X3 || precision == MT_PREC_BF16X6, "mt_weight_pack_halo: precision");
+  MT_REQUIRE(precision == MT_PREC_BF16X3 || precision == MT_PREC_BF16X6 || precision == MT_PREC_F16X3,
+             "mt_weight_pack_halo: precision");
+  MT_REQUIRE((precision == MT_PREC_F16X3) == (w_amax != nullptr), "mt_weight_pack_halo: w_amax goes with F16X3");
   const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = NS == 3 ? 16 : 32;
   const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);        // the n-tile igemm_halo uses for Co = AP
   const int nchunk = (BP + CK - 1) / CK, ntile = (AP + BN - 1) / BN;
   const long total = (long)T * nchunk * ntile * BN * (CK + 8);
   hipLaunchKernelGGL(weight_pack_halo_kernel, dim3(mt_grid_1d(total, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), src, A, B, T, (long)sa, (long)sb, (long)st,
-                     reinterpret_cast<__bf16*>(dst), BN, CK, NS, nchunk, ntile, flip);
+                     reinterpret_cast<__bf16*>(dst), BN, CK, NS, nchunk, ntile, flip, w_amax);
   return mt_check_launch("mt_weight_pack_halo");
 }

@@ -458,6 +458,43 @@ __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, lo
   }
 }
 
+// max |x| into a device scalar (non-negative floats order like their bit patterns)
+__device__ __forceinline__ void block_amax(float v, float* out) {
+  __shared__ float part[8];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, part[i]);
+    atomicMax(reinterpret_cast<int*>(out), __float_as_int(m));
+  }
+}
+
+__global__ void absmax_view_kernel(const float* x, long sn, long sh, long sw, int N, int H, int W, int C4, float* out) {
+  const long total = (long)N * H * W * C4;
+  float m = 0.f;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    int c = (int)(e % C4) * 4;
+    long r = e / C4;
+    int xx = (int)(r % W);
+    r /= W;
+    int yy = (int)(r % H);
+    int n = (int)(r / H);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + n * sn + yy * sh + xx * sw + c);
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+  block_amax(m, out);
+}
+
+__global__ void absmax_flat_kernel(const float* x, long n, float* out) {
+  float m = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[i]));
+  block_amax(m, out);
+}
+
 // row-wise masked L2 normalisation of NHWC4 features (correlation prologue):
 // out[p][c] = x[p][c]*v[p] / (||x[p]*v[p]||_2 + 1e-9); one wave per pixel row
 __global__ void rownorm_kernel(const float* x, long xn, long xh, long xw, int H, int W, int C, const float* v,
@@ -685,4 +722,18 @@ extern "C" int mt_adam_step_dev(float* p, const float* g, float* m, float* v, in
   hipLaunchKernelGGL(adam_dev_kernel, dim3(mt_grid_1d(n, 256)), dim3(256), 0, S_(stream), p, g, m, v, (long)n, beta1,
                      beta2, eps, grad_scale, state);
   return mt_check_launch("mt_adam_step_dev");
+}
+
+extern "C" int mt_absmax(const mt_view* x, float* out, void* stream) {
+  MT_REQUIRE(mt_view_flat(x) && out, "mt_absmax: bad arguments");
+  const long total = (long)x->N * x->H * x->W * (x->C / 4);
+  hipLaunchKernelGGL(absmax_view_kernel, dim3(mt_grid_1d(total, 256, 2048)), dim3(256), 0, S_(stream), x->p,
+                     (long)x->sn, (long)x->sh, (long)x->sw, x->N, x->H, x->W, x->C / 4, out);
+  return mt_check_launch("mt_absmax");
+}
+
+extern "C" int mt_absmax_flat(const float* p, int64_t n, float* out, void* stream) {
+  MT_REQUIRE(p && out && n > 0, "mt_absmax_flat: bad arguments");
+  hipLaunchKernelGGL(absmax_flat_kernel, dim3(mt_grid_1d(n, 256, 1024)), dim3(256), 0, S_(stream), p, (long)n, out);
+  return mt_check_launch("mt_absmax_flat");
 }

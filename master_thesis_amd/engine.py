@@ -17,13 +17,16 @@ WEIGHT_EPOCH = 0          # bumped by the optimizer: packed-weight cache key
 _pack_cache = {}
 PROFILE = None            # list -> every conv-engine launch appends (kernel, flops, ev0, ev1)
 # MFMA arithmetic of the conv engine (include/mt355.h, mt_precision):
-#   'bf16x6'  3-term bf16 split, 6 partial products: fp32-equivalent (default)
-#   'bf16x3'  2-term split, 3 partial products: ~4e-6 relative per layer
+#   'f16x3'   2-term fp16 split of power-of-two scaled tensors, 3 partial products:
+#             ~7e-8 relative per product (fp32-grade).  Halo-tile kernels only;
+#             every other layer of the step falls back to bf16x6.  (default)
+#   'bf16x6'  3-term bf16 split, 6 partial products: fp32-equivalent
+#   'bf16x3'  2-term bf16 split, 3 partial products: ~4e-6 relative per layer
 #   'f32'     fp32-input MFMA
-PRECISION = os.environ.get('MT355_PRECISION', 'bf16x6')
+PRECISION = os.environ.get('MT355_PRECISION', 'f16x3')
 # The VGG feature passes are never differentiated (model_vgg.py:43 detaches, and
 # model_dfpn.py:242,510 run them under no_grad) and feed only smooth functions
-# (cosine correlation, L1 of features): they run the cheaper 2-term split
+# (cosine correlation, L1 of features): they run the cheaper 2-term bf16 split
 # (~4e-6 relative per layer, far inside the 1e-3 output bar).  The DFPN aligner
 # inside the CHN step is also under no_grad, but its flow goes through a
 # NEAREST-neighbour warp of the visibility maps: extra rounding noise there
@@ -31,12 +34,16 @@ PRECISION = os.environ.get('MT355_PRECISION', 'bf16x6')
 PRECISION_VGG = os.environ.get('MT355_PRECISION_VGG', 'bf16x3')
 PRECISION_NOGRAD = os.environ.get('MT355_PRECISION_NOGRAD', 'same')
 USE_HALO = os.environ.get('MT355_HALO', '1') != '0'   # LDS halo-tile kernel for stride-1 3x3/5x5 layers
-_PREC = {'f32': L.PREC_F32, 'bf16x3': L.PREC_BF16X3, 'bf16x6': L.PREC_BF16X6}
+_PREC = {'f32': L.PREC_F32, 'bf16x3': L.PREC_BF16X3, 'bf16x6': L.PREC_BF16X6, 'f16x3': L.PREC_F16X3}
 _KTAG = {'f32': '', 'bf16x3': ',2', 'bf16x6': ',3'}
+_HTAG = {'bf16x3': '2,bf16', 'bf16x6': '3,bf16', 'f16x3': '2,f16'}
 
 
-def _prec():
-    return _PREC[PRECISION]
+def eff_precision(halo):
+    """Precision a launch really uses: f16x3 exists on the halo kernels only."""
+    if PRECISION == 'f16x3' and not halo:
+        return 'bf16x6'
+    return PRECISION
 
 
 def nograd_precision():
@@ -74,13 +81,12 @@ def halo_eligible(kind_fwd_like, stride, k, cin_p):
     return USE_HALO and PRECISION != 'f32' and kind_fwd_like and stride == 1 and k in (3, 5) and cin_p % 8 == 0
 
 
-def _igemm_name(co, d=None):
+def _igemm_name(co, halo, prec):
     cfg = '2,2,2,2' if co > 64 else ('2,2,2,1' if co > 32 else '4,1,1,1')
-    if d is not None and PRECISION != 'f32' and d.algo == 0 and not d.transposed and d.stride == 1 \
-            and d.KH in (3, 5) and d.pad == d.KH // 2 and d.x.C % 8 == 0:
-        return f'igemm_halo_kernel<{d.KH},{_KTAG[PRECISION][1:]},{cfg}>'
-    base = 'igemm_kernel' if PRECISION == 'f32' else 'igemm_split_kernel'
-    return f'{base}<{cfg}{_KTAG[PRECISION]}>'
+    if halo:
+        return 'igemm_halo_kernel<{k},%s,%s>' % (_HTAG[prec], cfg)
+    base = 'igemm_kernel' if prec == 'f32' else 'igemm_split_kernel'
+    return f'{base}<{cfg}{_KTAG[prec]}>'
 
 
 class _Prof:
@@ -120,7 +126,9 @@ def view_of(t):
     window of a wider NHWC buffer is fine)."""
     assert t.dim() == 4 and t.stride(3) == 1 and t.dtype == torch.float32, (t.shape, t.stride())
     n, h, w, c = t.shape
-    return L.View(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2), n, h, w, c, n, 0)
+    v = L.View(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2), n, h, w, c, n, 0)
+    v._src = t
+    return v
 
 
 def swap_view(t, groups):
@@ -132,21 +140,49 @@ def swap_view(t, groups):
     p1 = n // groups
     p2 = h * w
     assert p1 * groups == n and p1 == p2
-    return L.View(t.data_ptr(), c, w * p2 * c, p2 * c, groups * p2, h, w, c, p2, p1 * p2 * c)
+    v = L.View(t.data_ptr(), c, w * p2 * c, p2 * c, groups * p2, h, w, c, p2, p1 * p2 * c)
+    v._src = t
+    return v
 
 
 def null_view():
     return L.View(0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
 
 
+# ------------------------------------------------------- tensor magnitudes --
+def new_amax(device):
+    return torch.zeros((1,), device=device, dtype=torch.float32)
+
+
+def absmax_into(t, amax):
+    """amax[0] = max(amax[0], max|t|) for an engine tensor / channel window."""
+    L.call('mt_absmax', C.byref(view_of(t)), L.ptr(amax), L.stream_ptr())
+    return amax
+
+
+def amax_of(t):
+    """Device scalar max|t| of an engine tensor, computed once per tensor object
+    (the f16x3 kernels derive their power-of-two scale from it)."""
+    a = getattr(t, '_mt_amax', None)
+    if a is None:
+        a = absmax_into(t, new_amax(t.device))
+        try:
+            t._mt_amax = a
+        except AttributeError:
+            pass
+    return a
+
+
 # ------------------------------------------------------------ weight packs --
-def _pack(w, a_dim, kind, flip=False, halo=False):
-    """[AP][T][BP] packed copy of a conv weight.  ``a_dim`` selects which of
-    the two leading dims of ``w`` becomes the GEMM's output-channel axis."""
-    key = (w.data_ptr(), w._version, kind, halo, PRECISION, WEIGHT_EPOCH)
+def _pack(w, a_dim, kind, prec, flip=False, halo=False):
+    """Packed copy of a conv weight for precision ``prec``: rows
+    [AP][T][BP] (fp32 / bf16 planes) or, for the halo kernel, per-tile LDS
+    images.  ``a_dim`` selects which of the two leading dims of ``w`` becomes
+    the GEMM's output-channel axis.  Returns (packed, w_amax or None)."""
+    key = (w.data_ptr(), w._version, kind, halo, prec, WEIGHT_EPOCH)
     hit = _pack_cache.get(key)
     if hit is not None:
-        return hit[0]
+        return hit[0], hit[2]
     d0, d1, kh, kw = w.shape
     t = kh * kw
     assert w.is_contiguous()
@@ -154,23 +190,29 @@ def _pack(w, a_dim, kind, flip=False, halo=False):
         a, b, sa, sb = d0, d1, d1 * t, t
     else:
         a, b, sa, sb = d1, d0, t, d1 * t
+    wa = None
     if halo:
-        n = L.load().mt_weight_pack_halo_elems(cpad(a), cpad(b), t, _prec())
+        assert prec != 'f32'
+        if prec == 'f16x3':
+            wa = new_amax(w.device)
+            L.call('mt_absmax_flat', L.ptr(w), w.numel(), L.ptr(wa), L.stream_ptr())
+        n = L.load().mt_weight_pack_halo_elems(cpad(a), cpad(b), t, _PREC[prec])
         out = torch.empty((n,), device=w.device, dtype=torch.bfloat16)
-        L.call('mt_weight_pack_halo', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _prec(),
-               1 if flip else 0, L.stream_ptr())
-    elif PRECISION != 'f32':
+        L.call('mt_weight_pack_halo', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _PREC[prec],
+               1 if flip else 0, L.ptr(wa), L.stream_ptr())
+    elif prec != 'f32':
+        assert prec in ('bf16x3', 'bf16x6')
         kp = (t * cpad(b) + 31) // 32 * 32
-        out = torch.empty((3 if PRECISION == 'bf16x6' else 2, cpad(a), kp), device=w.device, dtype=torch.bfloat16)
-        L.call('mt_weight_pack_split', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _prec(),
+        out = torch.empty((3 if prec == 'bf16x6' else 2, cpad(a), kp), device=w.device, dtype=torch.bfloat16)
+        L.call('mt_weight_pack_split', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _PREC[prec],
                1 if flip else 0, L.stream_ptr())
     else:
         out = torch.empty((cpad(a), t, cpad(b)), device=w.device, dtype=torch.float32)
         L.call('mt_weight_pack', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), L.stream_ptr())
     # the entry keeps ``w`` alive so that its address cannot be recycled for a
     # different weight while the key is valid (cleared every optimizer step)
-    _pack_cache[key] = (out, w)
-    return out
+    _pack_cache[key] = (out, w, wa)
+    return out, wa
 
 
 def _pad_bias(b, n):
@@ -206,8 +248,17 @@ class LayerSpec:
                 (w - 1) * self.stride - 2 * self.pad + self.k + 1)
 
 
-def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.0):
-    """Run one layer forward.  xv: mt_view of the input; x_shape (N,H,W)."""
+def _amax_ptr(prec, explicit, view):
+    if prec != 'f16x3':
+        return None, None
+    a = explicit if explicit is not None else amax_of(view._src)
+    return a.data_ptr(), a
+
+
+def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.0, x_amax=None):
+    """Run one layer forward.  xv: mt_view of the input; x_shape (N,H,W).
+    ``x_amax``: device scalar >= max|x| (defaults to amax_of the view's tensor;
+    pass it for channel windows of a shared buffer)."""
     n, h, w_ = x_shape
     ho, wo = spec.out_hw(h, w_)
     if out is None:
@@ -215,7 +266,9 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
     d = L.Conv()
     d.x, d.y = xv, view_of(out)
     halo = halo_eligible(spec.kind == 'c', spec.stride, spec.k, xv.C)
-    d.wt = _pack(w, 0 if spec.kind == 'c' else 1, 'f', halo=halo).data_ptr()
+    prec = eff_precision(halo)
+    packed, wa = _pack(w, 0 if spec.kind == 'c' else 1, 'f', prec, halo=halo)
+    d.wt = packed.data_ptr()
     d.wt_layout = 1 if halo else 0
     pb = _pad_bias(b, spec.cout)
     d.bias = pb.data_ptr() if pb is not None else None
@@ -226,28 +279,34 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
     d.res = view_of(res) if res is not None else null_view()
     d.beta = beta
     d.dsrc = null_view()
-    d.precision = _prec()
+    d.precision = _PREC[prec]
     d.algo = 0 if USE_HALO else 1
+    d.x_amax, keep = _amax_ptr(prec, x_amax, xv)
+    d.w_amax = wa.data_ptr() if wa is not None else None
     if spec.kind == 'c':
         flops = 2.0 * n * ho * wo * spec.cin * spec.cout * spec.k * spec.k
     else:
         flops = 2.0 * n * h * w_ * spec.cin * spec.cout * spec.k * spec.k
-    with _Prof(_igemm_name(d.y.C, d), flops):
+    with _Prof(_igemm_name(d.y.C, halo, prec).replace('{k}', str(spec.k)), flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
     return out
 
 
-def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, accumulate=False, alpha=1.0):
+def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, accumulate=False, alpha=1.0,
+                       dz_amax=None):
     """dIn = bwd-data(dZ) written through the view ``yv`` (the layer's input
     geometry), optionally gated by act'(dsrc) (the previous layer's saved
     output)."""
     d = L.Conv()
-    d.x, d.y = view_of(dz), yv
+    dzv = view_of(dz)
+    d.x, d.y = dzv, yv
     # the backward-data of a stride-1 "same" Conv2d is itself a stride-1 "same"
     # convolution with tap-flipped, channel-swapped weights: run it as a forward
     # conv so that it takes the halo-tile kernel
     as_fwd = halo_eligible(spec.kind == 'c', spec.stride, spec.k, dz.shape[3])
-    d.wt = _pack(w, 1 if spec.kind == 'c' else 0, 'bflip' if as_fwd else 'b', flip=as_fwd, halo=as_fwd).data_ptr()
+    prec = eff_precision(as_fwd)
+    packed, wa = _pack(w, 1 if spec.kind == 'c' else 0, 'bflip' if as_fwd else 'b', prec, flip=as_fwd, halo=as_fwd)
+    d.wt = packed.data_ptr()
     d.wt_layout = 1 if as_fwd else 0
     d.bias = None
     d.KH = d.KW = spec.k
@@ -258,11 +317,13 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     d.dsrc = view_of(dsrc) if dsrc is not None else null_view()
     d.dact, d.dact_c0 = dact, dact_c0
     d.accumulate = 1 if accumulate else 0
-    d.precision = _prec()
+    d.precision = _PREC[prec]
     d.algo = 0 if USE_HALO else 1
+    d.x_amax, keep = _amax_ptr(prec, dz_amax, dzv)
+    d.w_amax = wa.data_ptr() if wa is not None else None
     side = d.x if spec.kind == 'c' else yv          # the conv's output side
     flops = 2.0 * side.N * side.H * side.W * spec.cin * spec.cout * spec.k * spec.k
-    with _Prof(_igemm_name(yv.C, d), flops):
+    with _Prof(_igemm_name(yv.C, as_fwd, prec).replace('{k}', str(spec.k)), flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
 
 
@@ -271,24 +332,26 @@ def _splits(blocks_base, pixels):
     return max(1, min(s, 512))
 
 
-def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0):
+def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_amax=None, x_amax=None):
     """(dW, db) of one layer.  dz: (N,Ho,Wo,CoP) gradient wrt the layer's
     pre-activation output; xin_view: mt_view of the layer's input."""
     dzv = view_of(dz)
     if spec.kind == 'c':
         dv, gv, a, b = dzv, xin_view, spec.cout, spec.cin
+        da, ga = dz_amax, x_amax
     else:
         dv, gv, a, b = xin_view, dzv, spec.cin, spec.cout
+        da, ga = x_amax, dz_amax
     ap, bp, t = cpad(a), cpad(b), spec.k * spec.k
     # tiles as chosen by wgrad_cfg in conv.hip
     if ap > 64 and bp > 64:
-        tiles = ((ap + 127) // 128) * ((bp + 127) // 128)
+        tiles, wcfg = ((ap + 127) // 128) * ((bp + 127) // 128), '2,2,2,2'
     elif ap <= 32:
-        tiles = (bp + 127) // 128
+        tiles, wcfg = (bp + 127) // 128, '1,4,1,1'
     elif bp <= 32:
-        tiles = (ap + 127) // 128
+        tiles, wcfg = (ap + 127) // 128, '4,1,1,1'
     else:
-        tiles = ((ap + 63) // 64) * ((bp + 63) // 64)
+        tiles, wcfg = ((ap + 63) // 64) * ((bp + 63) // 64), '2,2,1,1'
     pixels = dv.N * dv.H * dv.W
     d = L.Wgrad()
     d.d, d.g = dv, gv
@@ -296,6 +359,7 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0):
     d.stride, d.pad = spec.stride, spec.pad
     d.ups = spec.ups if spec.kind == 'c' else 0
     halo = USE_HALO and PRECISION != 'f32' and spec.stride == 1 and spec.k in (3, 5)
+    prec = eff_precision(halo)
     if halo:   # wgrad_halo_kernel: 64 x 64 channel tiles, all taps (3x3) or one kernel row (5x5) per block
         blocks = ((ap + 63) // 64) * ((bp + 63) // 64) * (1 if spec.k == 3 else 5)
         ntiles = dv.N * ((dv.H + 3) // 4) * ((dv.W + 15) // 16)
@@ -309,19 +373,13 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0):
     ts = t + (1 if fused_bias else 0)
     slabs = torch.empty((d.splits * ap * ts * bp,), device=w.device, dtype=torch.float32)
     d.slabs = slabs.data_ptr()
-    d.precision = _prec()
-    wbase = 'wgrad_kernel' if PRECISION == 'f32' else 'wgrad_split_kernel'
-    if ap > 64 and bp > 64:
-        wcfg = '2,2,2,2'
-    elif ap <= 32:
-        wcfg = '1,4,1,1'
-    elif bp <= 32:
-        wcfg = '4,1,1,1'
-    else:
-        wcfg = '2,2,1,1'
-    kname = f'{wbase}<{wcfg}{_KTAG[PRECISION]}>'
+    d.precision = _PREC[prec]
+    d.d_amax, keep1 = _amax_ptr(prec, da, dv)
+    d.g_amax, keep2 = _amax_ptr(prec, ga, gv)
     if halo:
-        kname = f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else 1},{_KTAG[PRECISION][1:]}>'
+        kname = f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else 1},{_HTAG[prec]}>'
+    else:
+        kname = ('wgrad_kernel' if prec == 'f32' else 'wgrad_split_kernel') + f'<{wcfg}{_KTAG[prec]}>'
     with _Prof(kname, 2.0 * pixels * spec.cin * spec.cout * t):
         L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
     dw = torch.empty_like(w)

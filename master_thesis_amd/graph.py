@@ -27,6 +27,10 @@ class GraphedTrainStep:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # nothing of the warm-up steps may survive into the capture: a live autograd
+        # graph would carry AccumulateGrad nodes bound to the side stream
+        import gc
+        gc.collect()
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad()
         with torch.cuda.graph(self.graph):
@@ -35,6 +39,8 @@ class GraphedTrainStep:
             self.loss.backward()
             if include_optimizer:
                 self.opt.step()
+        if include_optimizer:
+            self.opt.step_count -= 1           # capturing records the update, it does not run it
 
     def _eager(self):
         self.opt.zero_grad()

@@ -19,7 +19,8 @@ except Exception:  # noqa: BLE001
             self.current_epoch = 0
 
         def log(self, name, value, *args, **kwargs):
-            self.logged[name] = value
+            # detached: a logged loss must not keep its autograd graph alive
+            self.logged[name] = value.detach() if torch.is_tensor(value) else value
 
         @classmethod
         def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict=True, **kwargs):

@@ -49,10 +49,13 @@ class RRDBNetFn(torch.autograd.Function):
         cw = nf + 4 * gc
         saved = {}
 
-        def conv(key, xin, cin, cout, stride=1, act=NONE, ups=0, out=None, res=None, alpha=1.0, beta=0.0):
+        f16 = E.PRECISION == 'f16x3'     # the f16x3 kernels need max|x| of every conv input
+
+        def conv(key, xin, cin, cout, stride=1, act=NONE, ups=0, out=None, res=None, alpha=1.0, beta=0.0,
+                 x_amax=None):
             sp = E.LayerSpec('c', cin, cout, 3, stride, act, ups)
             return E.conv_forward(sp, E.view_of(xin), xin.shape[:3], P[key + '.weight'], P[key + '.bias'], out=out,
-                                  res=res, alpha=alpha, beta=beta)
+                                  res=res, alpha=alpha, beta=beta, x_amax=x_amax)
 
         # conv_first: five plain convs (two stride-2), no activation (:522-528)
         cur, first = x4, [x4]
@@ -65,31 +68,42 @@ class RRDBNetFn(torch.autograd.Function):
         def new_buf():
             return torch.empty((n, h, w, cw), device=f0.device, dtype=torch.float32)
 
+        def track(window, amax):     # running max|.| of everything written into a dense-block buffer
+            if f16:
+                E.absmax_into(window, amax)
+
         bufs = []
-        buf = new_buf()
+        buf, buf_amax = new_buf(), E.new_amax(f0.device)
         buf[..., :nf].copy_(f0)
+        track(buf[..., :nf], buf_amax)
         for k in range(nb):
             rrdb_x = buf[..., :nf]
             for j in (1, 2, 3):
                 key = f'rrdb_trunk.{k}.rdb{j}.'
                 for i in range(1, 5):
-                    conv(f'{key}conv{i}', buf[..., :nf + (i - 1) * gc], nf + (i - 1) * gc, gc, act=LRELU,
-                         out=buf[..., nf + (i - 1) * gc: nf + i * gc])
-                nxt = new_buf()
+                    dst = buf[..., nf + (i - 1) * gc: nf + i * gc]
+                    conv(f'{key}conv{i}', buf[..., :nf + (i - 1) * gc], nf + (i - 1) * gc, gc, act=LRELU, out=dst,
+                         x_amax=buf_amax)
+                    track(dst, buf_amax)
+                nxt, nxt_amax = new_buf(), E.new_amax(f0.device)
                 # 0.2 * conv5(cat) + x  (:623) written as the next block's x
-                conv(f'{key}conv5', buf, cw, nf, out=nxt[..., :nf], res=buf[..., :nf], alpha=0.2, beta=1.0)
-                bufs.append(buf)
-                buf = nxt
+                conv(f'{key}conv5', buf, cw, nf, out=nxt[..., :nf], res=buf[..., :nf], alpha=0.2, beta=1.0,
+                     x_amax=buf_amax)
+                bufs.append((buf, buf_amax))
+                buf, buf_amax = nxt, nxt_amax
+                if j < 3:
+                    track(buf[..., :nf], buf_amax)
             # 0.2 * y + x  (:585), in place in the next block's x window
             _axpby(buf[..., :nf], 0.2, rrdb_x, 1.0, buf[..., :nf])
+            track(buf[..., :nf], buf_amax)
         z = buf[..., :nf]
-        y = conv('trunk_conv', z, nf, nf, res=f0, alpha=1.0, beta=1.0)          # (:548)
+        y = conv('trunk_conv', z, nf, nf, res=f0, alpha=1.0, beta=1.0, x_amax=buf_amax)   # (:548)
         u1 = conv('upconv1', y, nf, nf, act=LRELU, ups=1)                        # (:549-551)
         u2 = conv('upconv2', u1, nf, nf, act=LRELU, ups=1)                       # (:552-554)
         hr = conv('hr_conv', u2, nf, nf, act=LRELU)
         out = conv('conv_last', hr, nf, net.out_nc)                              # (:555)
         if keep:
-            saved = dict(first=first, bufs=bufs, z=buf, y=y, u1=u1, u2=u2, hr=hr)
+            saved = dict(first=first, bufs=bufs, z=buf, z_amax=buf_amax, y=y, u1=u1, u2=u2, hr=hr)
         return out, saved
 
     @staticmethod
@@ -103,8 +117,8 @@ class RRDBNetFn(torch.autograd.Function):
         def spec(cin, cout, stride=1, ups=0):
             return E.LayerSpec('c', cin, cout, 3, stride, NONE, ups)
 
-        def wgrad(key, sp, dz, xin, scale=1.0):
-            dw, db = E.conv_backward_weight(sp, dz, E.view_of(xin), P[key + '.weight'], scale=scale)
+        def wgrad(key, sp, dz, xin, scale=1.0, x_amax=None):
+            dw, db = E.conv_backward_weight(sp, dz, E.view_of(xin), P[key + '.weight'], scale=scale, x_amax=x_amax)
             G[key + '.weight'], G[key + '.bias'] = dw, db
 
         def bdata(key, sp, dz, dx, **kw):
@@ -131,7 +145,7 @@ class RRDBNetFn(torch.autograd.Function):
         dy = dz                                              # grad wrt y = f0 + trunk_conv(z)
         n, h, w, _ = dy.shape
         sp = spec(nf, nf)
-        wgrad('trunk_conv', sp, dy, zbuf[..., :nf])
+        wgrad('trunk_conv', sp, dy, zbuf[..., :nf], x_amax=S['z_amax'])
         dcur = bdata('trunk_conv', sp, dy, torch.empty_like(dy))      # grad wrt the trunk output
         dbuf = torch.empty((n, h, w, cw), device=dy.device, dtype=torch.float32)
         bufs = S['bufs']
@@ -140,17 +154,17 @@ class RRDBNetFn(torch.autograd.Function):
             d_rdb, s_rdb = drr, 0.2                           # grad wrt rdb3's output = 0.2 * drr
             for j in (3, 2, 1):
                 key = f'rrdb_trunk.{k}.rdb{j}.'
-                buf = bufs[3 * k + (j - 1)]
+                buf, buf_amax = bufs[3 * k + (j - 1)]
                 # out = 0.2 * conv5(cat) + x  with d(out) = s_rdb * d_rdb
                 sp5 = spec(cw, nf)
-                wgrad(f'{key}conv5', sp5, d_rdb, buf, scale=0.2 * s_rdb)
+                wgrad(f'{key}conv5', sp5, d_rdb, buf, scale=0.2 * s_rdb, x_amax=buf_amax)
                 E.conv_backward_data(sp5, d_rdb, P[f'{key}conv5.weight'], E.view_of(dbuf), dsrc=buf, dact=LRELU,
                                      dact_c0=nf + 3 * gc, alpha=0.2 * s_rdb)
                 for i in (4, 3, 2, 1):
                     cin = nf + (i - 1) * gc
                     spi = spec(cin, gc)
                     dzi = dbuf[..., cin: cin + gc]
-                    wgrad(f'{key}conv{i}', spi, dzi, buf[..., :cin])
+                    wgrad(f'{key}conv{i}', spi, dzi, buf[..., :cin], x_amax=buf_amax)
                     E.conv_backward_data(spi, dzi, P[f'{key}conv{i}.weight'], E.view_of(dbuf[..., :cin]), dsrc=buf,
                                          dact=LRELU if i > 1 else NONE, dact_c0=cin - gc if i > 1 else 0,
                                          accumulate=True)

@@ -24,5 +24,5 @@ def bench(n,h,w,cin,cout,k,prec,halo=True,reps=5, kind='fwd'):
 if __name__ == '__main__':
     shapes = [(32,256,256,128,128,3), (8192,16,16,256,256,3), (32,64,64,160,32,3), (32,64,64,192,64,3), (32,256,256,128,128,5)]
     for sh in shapes:
-        for prec in ('bf16x3','bf16x6'):
+        for prec in ('bf16x3','bf16x6','f16x3'):
             bench(*sh, prec, True, kind=sys.argv[1] if len(sys.argv)>1 else 'fwd')

@@ -11,7 +11,7 @@ for (n,h,w,cin,cout,k) in [(2,32,32,128,128,3), (2,32,32,64,32,3), (2,32,32,12,6
     yr = F.conv2d(xr, wr, bs.double(), padding=k//2)
     gy = S.uniform('gy', tuple(yr.shape), -1, 1)
     yr.backward(gy.double())
-    for prec in ('f32', 'bf16x3', 'bf16x6'):
+    for prec in ('f32', 'bf16x3', 'bf16x6', 'f16x3'):
         E.PRECISION = prec
         spec = E.LayerSpec('c', cin, cout, k, 1, 0)
         xg = x.to(dev).requires_grad_(True); wg = wt.to(dev).requires_grad_(True); bg = bs.to(dev).requires_grad_(True)

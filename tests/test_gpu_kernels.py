@@ -68,7 +68,7 @@ def _torch_layer(x, w, b, k, stride, kind, act):
     return y
 
 
-@pytest.fixture(params=['f32', 'bf16x3', 'bf16x6'])
+@pytest.fixture(params=['f32', 'bf16x3', 'bf16x6', 'f16x3'])
 def precision(request):
     from master_thesis_amd import engine as E
     old = E.PRECISION
@@ -117,7 +117,9 @@ def test_conv_forward_backward(mt, case, precision):
     d = L.Conv()
     out2 = torch.empty_like(y4)
     d.x, d.y = E.view_of(x4.detach()), E.view_of(out2)
-    d.wt = E._pack(wg.detach(), 0 if kind == 'c' else 1, 'f').data_ptr()
+    if precision != 'f32':
+        return
+    d.wt = E._pack(wg.detach(), 0 if kind == 'c' else 1, 'f', 'f32')[0].data_ptr()
     d.bias = E._pad_bias(bg.detach(), cout).data_ptr()
     d.KH = d.KW = k
     d.stride, d.pad, d.transposed, d.act, d.alpha = stride, k // 2, 0 if kind == 'c' else 1, act, 1.0

@@ -251,3 +251,61 @@ def test_optimizer_step_moves_loss(mt, dfpn_sd):
         opt.step()
         losses.append(float(loss))
     assert np.isfinite(losses).all() and losses[-1] != losses[0], losses
+
+
+def test_graphed_step_matches_eager(mt, dfpn_sd):
+    """hipGraph replay of forward + losses + backward against the same step
+    launched eagerly: same loss, same gradients.  (After an Adam update the two
+    runs may drift apart legitimately: early Adam steps move EVERY parameter by
+    ~lr * sign(noise) wherever the gradient is at rounding level.)"""
+    from master_thesis_amd.graph import GraphedTrainStep
+    batch = to_dev(S.synthetic_batch(1, 2, 64, 64, seed=13, flows_use=[True]))
+
+    def fresh():
+        model = mt.DFPN(mt.VGGFeatures(device=DEV), **KW)
+        model.load_state_dict(dfpn_sd)
+        model = model.to(DEV)
+        return model, model.configure_optimizers()['optimizer']
+
+    m_e, o_e = fresh()
+    o_e.zero_grad()
+    loss_e = m_e.training_step(batch, 0)
+    loss_e.backward()
+    m_g, o_g = fresh()
+    g = GraphedTrainStep(m_g, o_g, batch, include_optimizer=False, warmup=1)
+    for _ in range(2):                      # replays are idempotent without the optimizer
+        loss_g = g.step()
+    np.testing.assert_allclose(float(loss_g), float(loss_e), rtol=1e-5)
+    ge, gg = o_e.flat_g, o_g.flat_g
+    assert float((ge - gg).norm() / ge.norm()) < 1e-4
+
+
+def test_device_side_adam_replays(mt):
+    """The capturable Adam (step counter and lr on the device) replayed from a
+    graph equals torch.optim.Adam step for step."""
+    ps = [S.uniform(f'gadam.p{i}', s, -1, 1) for i, s in enumerate([(5, 3, 3, 3), (5,), (33, 7)])]
+    grads = [S.uniform(f'gadam.g{i}', tuple(p.shape), -1, 1) for i, p in enumerate(ps)]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt_r = torch.optim.Adam(ref, lr=3e-3)
+    mine = [torch.nn.Parameter(p.to(DEV)) for p in ps]
+    opt = mt.FlatAdam(mine, lr=3e-3)
+    for a, gr in zip(mine, grads):
+        a.grad.copy_(gr.to(DEV))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        opt.step()                                  # one eager step first (step 1)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        opt.step()
+    opt.step_count -= 1
+    for _ in range(3):                              # steps 2..4 from the graph
+        graph.replay()
+        opt.step_count += 1
+    for _ in range(4):
+        for b, gr in zip(ref, grads):
+            b.grad = gr.clone()
+        opt_r.step()
+    for a, b in zip(mine, ref):
+        assert_close(a, b, 1e-5, 'adam from graph')
