@@ -27,7 +27,20 @@ sys.path.insert(0, ROOT)
 # SURVEY.md 8d / BASELINE.md section 4: algorithmic conv+GEMM work per step
 TFLOP_PER_STEP = {'dfpn': 43.31, 'chn': 30.71}
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32-input MFMA peak
+PEAK_16BIT_MFMA_TFLOPS = 2500.0      # dense bf16 / f16 MFMA peak (same guide)
 PEAK_HBM_GBS = 8000.0
+
+
+def cfg_tag(args, name):
+    return name + ': ' if (args.batch, args.frames, args.size) == (8, 5, 256) else ''
+
+
+def arithmetic_label():
+    from master_thesis_amd import engine as E
+    return (f'fp32 tensors; conv MFMA arithmetic {E.PRECISION} on the halo-tile kernels '
+            f'({"2-term fp16 split of power-of-two scaled operands, 3 f16 MFMA per product, ~7e-8 rel" if E.PRECISION == "f16x3" else E.PRECISION}), '
+            f'bf16x6 (3-term bf16 split, fp32-equivalent) on the strided/transposed layers, '
+            f'{E.vgg_precision()} on the never-differentiated VGG passes; fp32 accumulation everywhere')
 
 
 def parse():
@@ -105,7 +118,7 @@ def corr_roofline(b_pairs=2048):
     bytes_ = (b * c * p + b * r * c * p + (b + b * r) * p + b * r * p * p) * 4.0
     gbs = bytes_ / (ms * 1e-3) / 1e9
     flops = 2.0 * b * r * p * p * c
-    return {'kernel': 'mt_corr_masked (rownorm x2 + igemm_kernel<2,2,2,1>)', 'pairs': b * r, 'ms': ms,
+    return {'kernel': 'corr_fused_kernel (mt_corr_masked)', 'pairs': b * r, 'ms': ms,
             'bound': 'hbm', 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
             'tflops': flops / (ms * 1e-3) / 1e12}
 
@@ -205,7 +218,8 @@ def main():
         'metric': 'training frames/sec, 256x256x5 DFPN+CHN step', 'value': value, 'unit': 'frames/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'cfg2: DFPN train step (fwd+loss+bwd+allreduce+Adam), frames_n={args.frames}, '
+        'arithmetic': arithmetic_label(),
+        'config': {'workload': f'{cfg_tag(args, "cfg2")}DFPN train step (fwd+loss+bwd+allreduce+Adam), frames_n={args.frames}, '
                                f'{args.size}x{args.size}, batch_size={args.batch}/GPU',
                    'global_batch': args.batch * world, 'frames_n': args.frames, 'parallelism': f'dp{world}'},
         'launch': 'eager' if args.no_graph else 'hipGraph replay of the captured step',
@@ -220,8 +234,15 @@ def main():
         tot_ms = sum(a[1] for a in agg.values())
         name, (launches, kms, kfl) = max(agg.items(), key=lambda kv: kv[1][1])
         ach = kfl / (kms * 1e-3) / 1e12
-        out['roofline'] = {'kernel': name, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                           'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+        # MFMA products issued per fp32 multiply-add by the kernel's arithmetic
+        per = 3 if (',f16' in name or ',2,bf16' in name or name.endswith(',2>')) else (6 if 'split' in name or 'halo' in name else 1)
+        peak = PEAK_FP32_MFMA_TFLOPS if per == 1 else PEAK_16BIT_MFMA_TFLOPS / per
+        out['roofline'] = {'kernel': name, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
+                           'frac': ach / peak, 'traffic': None,
+                           'note': f'achieved = algorithmic conv FLOP / kernel time; peak = dense 16-bit MFMA peak '
+                                   f'{PEAK_16BIT_MFMA_TFLOPS:.0f} TFLOP/s / {per} MFMA products per fp32 multiply-add '
+                                   f'of this arithmetic (executed MFMA rate = {per} x achieved)' if per > 1 else
+                                   'fp32-input MFMA',
                            'launches_per_step': launches, 'avg_launch_ms': kms / launches,
                            'share_of_conv_engine_ms': kms / tot_ms}
         out['kernels'] = {k: {'launches': v[0], 'ms': round(v[1], 3), 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 2)}
@@ -256,7 +277,7 @@ def main():
 
         dtc = timed_steps(chn_step, args.steps, args.warmup, world)
         out['chn_train_step'] = {
-            'workload': f'cfg3: CHN train step (DFPN aligner), frames_n={args.frames}, {args.size}x{args.size}, '
+            'workload': f'{cfg_tag(args, "cfg3")}CHN train step (DFPN aligner), frames_n={args.frames}, {args.size}x{args.size}, '
                         f'batch_size={args.batch}/GPU',
             'value': frames_per_step * args.steps / dtc, 'unit': 'frames/s', 'ms_per_step': dtc / args.steps * 1e3}
         if rank == 0:

@@ -903,6 +903,138 @@ extern "C" int mt_pad_vector(const float* src, int32_t n, float* dst, int32_t np
   return mt_check_launch("mt_pad_vector");
 }
 
+namespace {
+// Fused masked cosine correlation of one (clip, reference) pair, P = 256
+// positions (CorrelationVGG.correlation_masked_4d, model_dfpn.py:534-565):
+//   out[pt][pr] = <t[pt], r[pr]> * ft[pt] * fr[pr],  f = v / (|v| * ||x|| + 1e-9)
+// ONE pass over HBM: the block streams the two [256][C] fp32 feature slabs in
+// 32-channel chunks (register prefetch, bf16x3 split into LDS), accumulates the
+// whole 256 x 256 output in the accumulator file (4 waves x 16 tiles of 32x32)
+// and the squared row norms on the side, and applies masks and norms in the
+// epilogue.  Algorithmic traffic only: 2 x 512 KiB in, 256 KiB out per pair
+// (the target slab is shared by the R pairs of a clip: the tile order keeps
+// them on one XCD's L2).
+__global__ __launch_bounds__(256, 1) void corr_fused_kernel(const float* ft, long tsn, long tsh, long tsw,
+                                                            const float* fr, long rsn, long rsh, long rsw, int W,
+                                                            int C, const float* vt, const float* vr, int R,
+                                                            float* out) {
+  constexpr int P = 256, CKC = 32, LD = CKC + 8, NS = 2;
+  __shared__ __attribute__((aligned(16))) __bf16 sT[NS][P * LD];
+  __shared__ __attribute__((aligned(16))) __bf16 sR[NS][P * LD];
+  __shared__ float nT[P], nR[P];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int pair = xcd_remap(blockIdx.x, gridDim.x);
+  const int clip = pair / R;
+  const float* tb = ft + (long)clip * tsn;
+  const float* rb = fr + (long)pair * rsn;
+  const int col4 = tid & 7, row0 = tid >> 3;
+  long toff[8], roff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int pix = row0 + 32 * i, y = pix / W, x = pix - y * W;
+    toff[i] = (long)y * tsh + (long)x * tsw + col4 * 4;
+    roff[i] = (long)y * rsh + (long)x * rsw + col4 * 4;
+  }
+  f32x4 rt[8], rr[8];
+  float qt[8], qr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) qt[i] = qr[i] = 0.f;
+  auto load_t = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rt[i] = *reinterpret_cast<const f32x4*>(tb + toff[i] + c0);
+  };
+  auto load_r = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rr[i] = *reinterpret_cast<const f32x4*>(rb + roff[i] + c0);
+  };
+  auto store_t = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      qt[i] += rt[i][0] * rt[i][0] + rt[i][1] * rt[i][1] + rt[i][2] * rt[i][2] + rt[i][3] * rt[i][3];
+      bf16x4 pt_[NS];
+      split4<NS>(rt[i], pt_);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sT[s][(row0 + 32 * i) * LD + col4 * 4]) = pt_[s];
+    }
+  };
+  auto store_r = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      qr[i] += rr[i][0] * rr[i][0] + rr[i][1] * rr[i][1] + rr[i][2] * rr[i][2] + rr[i][3] * rr[i][3];
+      bf16x4 pr_[NS];
+      split4<NS>(rr[i], pr_);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sR[s][(row0 + 32 * i) * LD + col4 * 4]) = pr_[s];
+    }
+  };
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int nchunk = C / CKC;
+  load_t(0);
+  load_r(0);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const bool more = ch + 1 < nchunk;
+    __syncthreads();                       // the previous chunk's fragments have been read
+    store_t();
+    if (more) load_t((ch + 1) * CKC);      // refill each register set as soon as it is consumed
+    store_r();
+    if (more) load_r((ch + 1) * CKC);
+    __syncthreads();
+    const int ao = (wm * 128 + li) * LD + 8 * lh, bo = (wn * 128 + li) * LD + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < CKC / 16; ++ks) {
+      bf16x8 fb[4][NS];
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fb[b][s] = *reinterpret_cast<const bf16x8*>(&sR[s][bo + b * 32 * LD + ks * 16]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        bf16x8 fa[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fa[s] = *reinterpret_cast<const bf16x8*>(&sT[s][ao + a * 32 * LD + ks * 16]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) mfma_split<NS>(fa, fb[b], acc[a][b]);
+      }
+    }
+  }
+  // row norms: the 8 threads of a row (consecutive lanes) combine their partial sums
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float a = qt[i], b = qr[i];
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (col4 == 0) {
+      const int pix = row0 + 32 * i;
+      const float v1 = vt ? vt[(long)clip * P + pix] : 1.f, v2 = vr ? vr[(long)pair * P + pix] : 1.f;
+      nT[pix] = v1 / (fabsf(v1) * sqrtf(a) + 1e-9f);
+      nR[pix] = v2 / (fabsf(v2) * sqrtf(b) + 1e-9f);
+    }
+  }
+  __syncthreads();
+  float* ob = out + (long)pair * P * P;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pt = wm * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float f1 = nT[pt];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int pr = wn * 128 + b * 32 + li;
+        ob[(long)pt * P + pr] = acc[a][b][r] * f1 * nR[pr];
+      }
+    }
+}
+}  // namespace
+
 extern "C" int mt_rownorm(const mt_view* x, const float* v, float* out, void* stream);
 
 // CorrelationVGG.correlation_masked_4d (model_dfpn.py:534-565): masked L2 row
@@ -915,6 +1047,13 @@ extern "C" int mt_corr_masked(const mt_view* ft, const mt_view* fr, const float*
              "mt_corr_masked: feature geometry mismatch");
   const int P = ft->H * ft->W, C = ft->C;
   MT_REQUIRE((P & 3) == 0 && B * R < 65536, "mt_corr_masked: P %% 4 != 0 or too many pairs");
+  if (P == 256 && (C % 32) == 0 && ft->n_in >= ft->N && fr->n_in >= fr->N) {
+    // fused single-pass kernel (the DFPN case: 16 x 16 positions)
+    hipLaunchKernelGGL(corr_fused_kernel, dim3(B * R), dim3(256), 0, static_cast<hipStream_t>(stream), ft->p,
+                       (long)ft->sn, (long)ft->sh, (long)ft->sw, fr->p, (long)fr->sn, (long)fr->sh, (long)fr->sw, ft->W,
+                       C, vt, vr, R, out);
+    return mt_check_launch("mt_corr_masked(fused)");
+  }
   float* tn = ws;
   float* rn = ws + (size_t)B * P * C;
   int rc = mt_rownorm(ft, vt, tn, stream);
