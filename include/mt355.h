@@ -232,7 +232,8 @@ int mt_dact(const mt_view* x, const mt_view* s, int32_t act, const mt_view* y,
  * vt: [B][P] visibility or NULL; vr: [B*R][P] or NULL;
  * out: [B*R][P_t][P_r] floats (== (B,R,h,w,h,w) contiguous);
  * ws: (B + B*R) * P * C floats of scratch (the normalised features); only the
- * general path uses it: for P = 256, C % 32 == 0 (the DFPN case) one fused
+ * general path uses it and it may be NULL otherwise: for P = 256, C % 64 == 0,
+ * C >= 128 and per-image extents below 256 MiB (the DFPN case) one fused
  * kernel streams both feature slabs once (bf16x3 MFMA, norms and masks in the
  * epilogue). */
 int mt_corr_masked(const mt_view* ft, const mt_view* fr, const float* vt,

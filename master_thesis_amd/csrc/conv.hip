@@ -908,111 +908,145 @@ namespace {
 // positions (CorrelationVGG.correlation_masked_4d, model_dfpn.py:534-565):
 //   out[pt][pr] = <t[pt], r[pr]> * ft[pt] * fr[pr],  f = v / (|v| * ||x|| + 1e-9)
 // ONE pass over HBM: the block streams the two [256][C] fp32 feature slabs in
-// 32-channel chunks (register prefetch, bf16x3 split into LDS), accumulates the
-// whole 256 x 256 output in the accumulator file (4 waves x 16 tiles of 32x32)
-// and the squared row norms on the side, and applies masks and norms in the
-// epilogue.  Algorithmic traffic only: 2 x 512 KiB in, 256 KiB out per pair
-// (the target slab is shared by the R pairs of a clip: the tile order keeps
-// them on one XCD's L2).
-__global__ __launch_bounds__(256, 1) void corr_fused_kernel(const float* ft, long tsn, long tsh, long tsw,
-                                                            const float* fr, long rsn, long rsh, long rsw, int W,
-                                                            int C, const float* vt, const float* vr, int R,
-                                                            float* out) {
-  constexpr int P = 256, CKC = 32, LD = CKC + 8, NS = 2;
-  __shared__ __attribute__((aligned(16))) __bf16 sT[NS][P * LD];
-  __shared__ __attribute__((aligned(16))) __bf16 sR[NS][P * LD];
-  __shared__ float nT[P], nR[P];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+// 32-channel chunks, splits them into bf16 hi/lo planes in LDS (bf16x3
+// products), accumulates the whole 256 x 256 output in registers and the
+// squared row norms on the side, and applies masks and norms in the epilogue.
+// Algorithmic traffic only: 2 x 512 KiB in, 256 KiB out per pair (the target
+// slab is shared by the R pairs of a clip and stays in L2).
+//
+// 512 threads = two groups of 4 waves, one wave of each group per SIMD.  The
+// LDS holds two chunk images (all 160 KiB).  While one group runs the MFMAs of
+// chunk k, the other splits + stores its share of chunk k+1 into the other
+// image, then the roles swap: the matrix pipe of every SIMD always has a wave
+// feeding it, and the VALU split runs in its shadow.  Each thread keeps two
+// register sets of prefetched chunks, so global loads are in flight all the
+// time (two chunks ahead).
+__global__ __launch_bounds__(512, 1) void corr_fused_kernel(const float* ft, long tsn, long tsh, long tsw,
+                                                         const float* fr, long rsn, long rsh, long rsw, int W,
+                                                         int C, const float* vt, const float* vr, int R,
+                                                         float* out) {
+  constexpr int P = 256, CKC = 32, LD = CKC + 8, NS = 2, NI = 4, PL = P * LD;
+  // [buf][T|R][plane][P*LD]  = 2*2*2*20480 B = 163840 B (all of the CU's LDS)
+  __shared__ __attribute__((aligned(16))) __bf16 sm[2 * 2 * NS * PL];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, wm = wave & 3, wn = g, li = lane & 31, lh = lane >> 5;
   const int pair = xcd_remap(blockIdx.x, gridDim.x);
   const int clip = pair / R;
-  const float* tb = ft + (long)clip * tsn;
-  const float* rb = fr + (long)pair * rsn;
+  // buffer descriptors (wave-uniform) of the two feature slabs: loads use a 32-bit lane byte
+  // offset + a scalar chunk offset, so no 64-bit address registers are held per load
+  const int H = P / W;
+  const unsigned tbytes = (unsigned)(((long)(H - 1) * tsh + (long)(W - 1) * tsw + C) * 4);
+  const unsigned rbytes = (unsigned)(((long)(H - 1) * rsh + (long)(W - 1) * rsw + C) * 4);
+  const auto srT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ft + (long)clip * tsn), 0, tbytes, 0x00020000);
+  const auto srR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fr + (long)pair * rsn), 0, rbytes, 0x00020000);
   const int col4 = tid & 7, row0 = tid >> 3;
-  long toff[8], roff[8];
+  unsigned toff[NI], roff[NI];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int pix = row0 + 32 * i, y = pix / W, x = pix - y * W;
-    toff[i] = (long)y * tsh + (long)x * tsw + col4 * 4;
-    roff[i] = (long)y * rsh + (long)x * rsw + col4 * 4;
+  for (int i = 0; i < NI; ++i) {
+    const int pix = row0 + 64 * i, y = pix / W, x = pix - y * W;
+    toff[i] = ((unsigned)((long)y * tsh + (long)x * tsw) + col4 * 4) * 4u;   // bytes
+    roff[i] = ((unsigned)((long)y * rsh + (long)x * rsw) + col4 * 4) * 4u;
   }
-  f32x4 rt[8], rr[8];
-  float qt[8], qr[8];
+  f32x4 rt[2][NI], rr[2][NI];
+  float qt[NI], qr[NI];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) qt[i] = qr[i] = 0.f;
-  auto load_t = [&](int c0) {
+  for (int i = 0; i < NI; ++i) qt[i] = qr[i] = 0.f;
+  auto load = [&](f32x4 (&t)[NI], f32x4 (&r)[NI], int c0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rt[i] = *reinterpret_cast<const f32x4*>(tb + toff[i] + c0);
+    for (int i = 0; i < NI; ++i) t[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srT, toff[i], c0 * 4, 0));
+#pragma unroll
+    for (int i = 0; i < NI; ++i) r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srR, roff[i], c0 * 4, 0));
   };
-  auto load_r = [&](int c0) {
+  auto store = [&](const f32x4 (&t)[NI], const f32x4 (&r)[NI], int buf) {
+    __bf16* bT = sm + buf * (2 * NS * PL);
+    __bf16* bR = bT + NS * PL;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rr[i] = *reinterpret_cast<const f32x4*>(rb + roff[i] + c0);
-  };
-  auto store_t = [&]() {
+    for (int i = 0; i < NI; ++i) {
+      qt[i] += t[i][0] * t[i][0] + t[i][1] * t[i][1] + t[i][2] * t[i][2] + t[i][3] * t[i][3];
+      bf16x4 p_[NS];
+      split4<NS>(t[i], p_);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      qt[i] += rt[i][0] * rt[i][0] + rt[i][1] * rt[i][1] + rt[i][2] * rt[i][2] + rt[i][3] * rt[i][3];
-      bf16x4 pt_[NS];
-      split4<NS>(rt[i], pt_);
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&bT[s * PL + (row0 + 64 * i) * LD + col4 * 4]) = p_[s];
+    }
 #pragma unroll
-      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sT[s][(row0 + 32 * i) * LD + col4 * 4]) = pt_[s];
+    for (int i = 0; i < NI; ++i) {
+      qr[i] += r[i][0] * r[i][0] + r[i][1] * r[i][1] + r[i][2] * r[i][2] + r[i][3] * r[i][3];
+      bf16x4 p_[NS];
+      split4<NS>(r[i], p_);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&bR[s * PL + (row0 + 64 * i) * LD + col4 * 4]) = p_[s];
     }
   };
-  auto store_r = [&]() {
+  f32x16 acc[2][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      qr[i] += rr[i][0] * rr[i][0] + rr[i][1] * rr[i][1] + rr[i][2] * rr[i][2] + rr[i][3] * rr[i][3];
-      bf16x4 pr_[NS];
-      split4<NS>(rr[i], pr_);
-#pragma unroll
-      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sR[s][(row0 + 32 * i) * LD + col4 * 4]) = pr_[s];
-    }
-  };
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-  const int nchunk = C / CKC;
-  load_t(0);
-  load_r(0);
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const bool more = ch + 1 < nchunk;
-    __syncthreads();                       // the previous chunk's fragments have been read
-    store_t();
-    if (more) load_t((ch + 1) * CKC);      // refill each register set as soon as it is consumed
-    store_r();
-    if (more) load_r((ch + 1) * CKC);
-    __syncthreads();
-    const int ao = (wm * 128 + li) * LD + 8 * lh, bo = (wn * 128 + li) * LD + 8 * lh;
+  const int ao = (wm * 64 + li) * LD + 8 * lh, bo = (wn * 128 + li) * LD + 8 * lh;
+  auto compute = [&](int buf) {
+    const __bf16* bT = sm + buf * (2 * NS * PL);
+    const __bf16* bR = bT + NS * PL;
 #pragma unroll
     for (int ks = 0; ks < CKC / 16; ++ks) {
-      bf16x8 fb[4][NS];
+      bf16x8 fa[2][NS];
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) fb[b][s] = *reinterpret_cast<const bf16x8*>(&sR[s][bo + b * 32 * LD + ks * 16]);
+        for (int s = 0; s < NS; ++s) fa[a][s] = *reinterpret_cast<const bf16x8*>(&bT[s * PL + ao + a * 32 * LD + ks * 16]);
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        bf16x8 fa[NS];
+      for (int b = 0; b < 4; ++b) {
+        bf16x8 fb[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) fa[s] = *reinterpret_cast<const bf16x8*>(&sT[s][ao + a * 32 * LD + ks * 16]);
+        for (int s = 0; s < NS; ++s) fb[s] = *reinterpret_cast<const bf16x8*>(&bR[s * PL + bo + b * 32 * LD + ks * 16]);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) mfma_split<NS>(fa, fb[b], acc[a][b]);
+        for (int a = 0; a < 2; ++a) mfma_split<NS>(fa[a], fb, acc[a][b]);
       }
     }
+  };
+  const int nchunk = C / CKC;   // even, >= 4
+  const int c_start = (2 * clip) % nchunk;
+  // channel offset of chunk c (rotated start); past the last chunk: beyond the descriptor's
+  // range, where a buffer load returns zeros without touching memory
+  auto choff = [&](int c) { int q = c + c_start; q = q >= nchunk ? q - nchunk : q; return c < nchunk ? q * CKC : (1 << 28); };
+  // Group g keeps chunk c in register set (c + g) & 1 and runs one phase behind/ahead of the
+  // other group:   g0: C0 | S1 | C1 | S2 | ...      g1: S1 | C0 | S2 | C1 | ...
+  // (Ck = MFMAs of chunk k from image k&1, Sk = split+store of the group's share of chunk k)
+  load(rt[0], rr[0], choff(g));
+  load(rt[1], rr[1], choff(1 - g));
+  if (g == 0) { store(rt[0], rr[0], 0); load(rt[0], rr[0], choff(2)); }
+  else        { store(rt[1], rr[1], 0); load(rt[1], rr[1], choff(2)); }
+  __syncthreads();
+  if (g == 1) {
+    store(rt[0], rr[0], 1);
+    load(rt[0], rr[0], choff(3));
+    __syncthreads();
   }
-  // row norms: the 8 threads of a row (consecutive lanes) combine their partial sums
+  for (int k = 0; k < nchunk; k += 2) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+    for (int h = 0; h < 2; ++h) {
+      const int cs = k + h + 1 + g;        // chunk this group stores in this step (register set h^1)
+      compute(h);
+      __syncthreads();
+      if (cs < nchunk) {
+        store(rt[h ^ 1], rr[h ^ 1], (h ^ 1) ^ g);
+      }
+      load(rt[h ^ 1], rr[h ^ 1], choff(cs + 2));
+      __syncthreads();
+    }
+  }
+  if (g == 0) __syncthreads();
+  float* nT = reinterpret_cast<float*>(sm);
+  float* nR = nT + P;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
     float a = qt[i], b = qr[i];
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
     if (col4 == 0) {
-      const int pix = row0 + 32 * i;
+      const int pix = row0 + 64 * i;
       const float v1 = vt ? vt[(long)clip * P + pix] : 1.f, v2 = vr ? vr[(long)pair * P + pix] : 1.f;
       nT[pix] = v1 / (fabsf(v1) * sqrtf(a) + 1e-9f);
       nR[pix] = v2 / (fabsf(v2) * sqrtf(b) + 1e-9f);
@@ -1021,10 +1055,10 @@ __global__ __launch_bounds__(256, 1) void corr_fused_kernel(const float* ft, lon
   __syncthreads();
   float* ob = out + (long)pair * P * P;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int pt = wm * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int pt = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const float f1 = nT[pt];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
@@ -1042,18 +1076,22 @@ extern "C" int mt_rownorm(const mt_view* x, const float* v, float* out, void* st
 // (clip, reference) pair, batched over blockIdx.z.
 extern "C" int mt_corr_masked(const mt_view* ft, const mt_view* fr, const float* vt, const float* vr, int32_t B,
                               int32_t R, float* out, float* ws, void* stream) {
-  MT_REQUIRE(mt_view_ok(ft) && mt_view_ok(fr) && out && ws, "mt_corr_masked: bad arguments");
+  MT_REQUIRE(mt_view_ok(ft) && mt_view_ok(fr) && out, "mt_corr_masked: bad arguments");
   MT_REQUIRE(ft->N == B && fr->N == B * R && ft->H == fr->H && ft->W == fr->W && ft->C == fr->C,
              "mt_corr_masked: feature geometry mismatch");
   const int P = ft->H * ft->W, C = ft->C;
   MT_REQUIRE((P & 3) == 0 && B * R < 65536, "mt_corr_masked: P %% 4 != 0 or too many pairs");
-  if (P == 256 && (C % 32) == 0 && ft->n_in >= ft->N && fr->n_in >= fr->N) {
+  const long text = ((long)(ft->H - 1) * ft->sh + (long)(ft->W - 1) * ft->sw + C) * 4;
+  const long rext = ((long)(fr->H - 1) * fr->sh + (long)(fr->W - 1) * fr->sw + C) * 4;
+  if (P == 256 && (C % 64) == 0 && C >= 128 && ft->n_in >= ft->N && fr->n_in >= fr->N && ft->W == fr->W &&
+      text < (1L << 28) && rext < (1L << 28)) {
     // fused single-pass kernel (the DFPN case: 16 x 16 positions)
-    hipLaunchKernelGGL(corr_fused_kernel, dim3(B * R), dim3(256), 0, static_cast<hipStream_t>(stream), ft->p,
+    hipLaunchKernelGGL(corr_fused_kernel, dim3(B * R), dim3(512), 0, static_cast<hipStream_t>(stream), ft->p,
                        (long)ft->sn, (long)ft->sh, (long)ft->sw, fr->p, (long)fr->sn, (long)fr->sh, (long)fr->sw, ft->W,
                        C, vt, vr, R, out);
     return mt_check_launch("mt_corr_masked(fused)");
   }
+  MT_REQUIRE(ws, "mt_corr_masked: the general path (not 16 x 16 positions) needs the workspace");
   float* tn = ws;
   float* rn = ws + (size_t)B * P * C;
   int rc = mt_rownorm(ft, vt, tn, stream);

@@ -182,7 +182,9 @@ def correlation(ft4, fr4, v_t, v_r, b, r):
     p = ft4.shape[1] * ft4.shape[2]
     cch = ft4.shape[3]
     out = torch.empty((b * r, p, p), device=ft4.device, dtype=torch.float32)
-    ws = torch.empty(((b + b * r) * p * cch,), device=ft4.device, dtype=torch.float32)
+    # the fused P = 256 kernel needs no workspace; the general path normalises into one
+    fused = p == 256 and cch % 64 == 0 and cch >= 128
+    ws = None if fused else torch.empty(((b + b * r) * p * cch,), device=ft4.device, dtype=torch.float32)
     if v_t is not None:
         v_t, v_r = v_t.contiguous(), v_r.contiguous()
     L.call('mt_corr_masked', C.byref(view_of(ft4)), C.byref(view_of(fr4)), L.ptr(v_t), L.ptr(v_r), b, r,

@@ -1,0 +1,221 @@
+#include "../../master_thesis_amd/csrc/conv_common.h"
+namespace {
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void corr_lab_kernel(const float* ft, long tsn, long tsh, long tsw,
+                                                            const float* fr, long rsn, long rsh, long rsw, int W,
+                                                            int C, const float* vt, const float* vr, int R,
+                                                            float* out) {
+  constexpr int P = 256, CKC = 32, LD = CKC + 8, NS = 2;
+  __shared__ __attribute__((aligned(16))) __bf16 sT[NS][P * LD];
+  __shared__ __attribute__((aligned(16))) __bf16 sR[NS][P * LD];
+  __shared__ float nT[P], nR[P];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int pair = xcd_remap(blockIdx.x, gridDim.x);
+  const int clip = pair / R;
+  const float* tb = ft + (long)clip * tsn;
+  const float* rb = fr + (long)pair * rsn;
+  const int col4 = tid & 7, row0 = tid >> 3;
+  long toff[8], roff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int pix = row0 + 32 * i, y = pix / W, x = pix - y * W;
+    toff[i] = (long)y * tsh + (long)x * tsw + col4 * 4;
+    roff[i] = (long)y * rsh + (long)x * rsw + col4 * 4;
+  }
+  f32x4 rt[8], rr[8];
+  float qt[8], qr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) qt[i] = qr[i] = 0.f;
+  auto load_t = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rt[i] = *reinterpret_cast<const f32x4*>(tb + toff[i] + c0);
+  };
+  auto load_r = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rr[i] = *reinterpret_cast<const f32x4*>(rb + roff[i] + c0);
+  };
+  auto store_t = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      qt[i] += rt[i][0] * rt[i][0] + rt[i][1] * rt[i][1] + rt[i][2] * rt[i][2] + rt[i][3] * rt[i][3];
+      bf16x4 pt_[NS];
+      split4<NS>(rt[i], pt_);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sT[s][(row0 + 32 * i) * LD + col4 * 4]) = pt_[s];
+    }
+  };
+  auto store_r = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      qr[i] += rr[i][0] * rr[i][0] + rr[i][1] * rr[i][1] + rr[i][2] * rr[i][2] + rr[i][3] * rr[i][3];
+      bf16x4 pr_[NS];
+      split4<NS>(rr[i], pr_);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sR[s][(row0 + 32 * i) * LD + col4 * 4]) = pr_[s];
+    }
+  };
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // Every block walks the channel chunks in a rotated order (start = clip mod
+  // nchunk): blocks run in near lock-step, and with all of them on the same
+  // 128-byte column of the 2-KiB pixel rows the requests camp on a fraction of
+  // the HBM channels.  The R pairs of a clip share the rotation so the target
+  // chunk they all read stays hot in L2.
+  const int nchunk = C / CKC;
+  int cc = clip % nchunk;
+  load_t(cc * CKC);
+  load_r(cc * CKC);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const bool more = ch + 1 < nchunk;
+    cc = cc + 1 == nchunk ? 0 : cc + 1;
+    __syncthreads();                       // the previous chunk's fragments have been read
+    store_t();
+    if (more && MODE != 2) load_t(cc * CKC);            // refill each register set as soon as it is consumed
+    store_r();
+    if (more && MODE != 2) load_r(cc * CKC);
+    __syncthreads();
+    if (MODE == 1) continue;
+    const int ao = (wm * 128 + li) * LD + 8 * lh, bo = (wn * 128 + li) * LD + 8 * lh;
+#pragma unroll
+    for (int ks = 0; ks < CKC / 16; ++ks) {
+      bf16x8 fb[4][NS];
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fb[b][s] = *reinterpret_cast<const bf16x8*>(&sR[s][bo + b * 32 * LD + ks * 16]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        bf16x8 fa[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fa[s] = *reinterpret_cast<const bf16x8*>(&sT[s][ao + a * 32 * LD + ks * 16]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) mfma_split<NS>(fa, fb[b], acc[a][b]);
+      }
+    }
+  }
+  // row norms: the 8 threads of a row (consecutive lanes) combine their partial sums
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float a = qt[i], b = qr[i];
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if (col4 == 0) {
+      const int pix = row0 + 32 * i;
+      const float v1 = vt ? vt[(long)clip * P + pix] : 1.f, v2 = vr ? vr[(long)pair * P + pix] : 1.f;
+      nT[pix] = v1 / (fabsf(v1) * sqrtf(a) + 1e-9f);
+      nR[pix] = v2 / (fabsf(v2) * sqrtf(b) + 1e-9f);
+    }
+  }
+  __syncthreads();
+  float* ob = out + (long)pair * P * P;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pt = wm * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float f1 = nT[pt];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int pr = wn * 128 + b * 32 + li;
+        if (MODE != 3 || acc[a][b][r] == 12345.f) ob[(long)pt * P + pr] = acc[a][b][r] * f1 * nR[pr];
+      }
+    }
+}
+#include "corr_v3.h"
+#include "corr_v4.h"
+#include "corr_v5.h"
+}
+
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1;}}while(0)
+template <int MODE> float run(const float* ft,const float* fr,const float* vt,const float* vr,float* out,int B,int R){
+  const int C=512,W=16; long sn=256L*C, sh=16L*C, sw=C;
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for(int i=0;i<2;++i) hipLaunchKernelGGL(corr_lab_kernel<MODE>, dim3(B*R), dim3(256), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  hipEventRecord(e0,0);
+  const int n=5;
+  for(int i=0;i<n;++i) hipLaunchKernelGGL(corr_lab_kernel<MODE>, dim3(B*R), dim3(256), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  hipEventRecord(e1,0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms,e0,e1); return ms/n;
+}
+template <int MODE> float run3(const float* ft,const float* fr,const float* vt,const float* vr,float* out,int B,int R){
+  const int C=512,W=16; long sn=256L*C, sh=16L*C, sw=C;
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for(int i=0;i<2;++i) hipLaunchKernelGGL(corr_v3_kernel<MODE>, dim3(B*R), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  hipEventRecord(e0,0);
+  const int n=5;
+  for(int i=0;i<n;++i) hipLaunchKernelGGL(corr_v3_kernel<MODE>, dim3(B*R), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  hipEventRecord(e1,0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms,e0,e1); return ms/n;
+}
+template <int MODE> float run5(const float* ft,const float* fr,const float* vt,const float* vr,float* out,int B,int R){
+  const int C=512,W=16; long sn=256L*C, sh=16L*C, sw=C;
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for(int i=0;i<2;++i) hipLaunchKernelGGL(corr_v5_kernel<MODE>, dim3(B*R), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  hipEventRecord(e0,0);
+  const int n=5;
+  for(int i=0;i<n;++i) hipLaunchKernelGGL(corr_v5_kernel<MODE>, dim3(B*R), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  hipEventRecord(e1,0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms,e0,e1); return ms/n;
+}
+template <int MODE> float run4(const float* ft,const float* fr,const float* vt,const float* vr,float* out,int B,int R){
+  const int C=512,W=16; long sn=256L*C, sh=16L*C, sw=C;
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for(int i=0;i<2;++i) hipLaunchKernelGGL(corr_v4_kernel<MODE>, dim3(B*R), dim3(256), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  hipEventRecord(e0,0);
+  const int n=5;
+  for(int i=0;i<n;++i) hipLaunchKernelGGL(corr_v4_kernel<MODE>, dim3(B*R), dim3(256), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  hipEventRecord(e1,0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms,e0,e1); return ms/n;
+}
+int main(int argc,char**argv){ int only = argc>1 ? atoi(argv[1]) : -1;
+  const int B=512,R=4,P=256,C=512;
+  float *ft,*fr,*vt,*vr,*out;
+  CK(hipMalloc(&ft,(size_t)B*P*C*4)); CK(hipMalloc(&fr,(size_t)B*R*P*C*4)); CK(hipMalloc(&vt,(size_t)B*P*4)); CK(hipMalloc(&vr,(size_t)B*R*P*4)); CK(hipMalloc(&out,(size_t)B*R*P*P*4));
+  std::vector<float> h((size_t)B*R*P*C); for(size_t i=0;i<h.size();++i) h[i]=(float)((i*2654435761u)%1000)/500.f-1.f;
+  CK(hipMemcpy(fr,h.data(),h.size()*4,hipMemcpyHostToDevice)); CK(hipMemcpy(ft,h.data(),(size_t)B*P*C*4,hipMemcpyHostToDevice));
+  std::vector<float> o((size_t)B*R*P,1.f); CK(hipMemcpy(vr,o.data(),o.size()*4,hipMemcpyHostToDevice)); CK(hipMemcpy(vt,o.data(),(size_t)B*P*4,hipMemcpyHostToDevice));
+  double bytes=((double)B*C*P+(double)B*R*C*P+(double)(B+B*R)*P+(double)B*R*P*P)*4.0;
+  float t;
+  { // cross-check v5 against v1 (masks random-ish)
+    std::vector<float> mv((size_t)B*R*P); for(size_t i=0;i<mv.size();++i) mv[i]=((i*7919u)%10)<1?0.f:1.f;
+    CK(hipMemcpy(vr,mv.data(),mv.size()*4,hipMemcpyHostToDevice)); CK(hipMemcpy(vt,mv.data()+777,(size_t)B*P*4,hipMemcpyHostToDevice));
+    const size_t n=(size_t)64*P*P; std::vector<float> o1(n), o5(n);
+    const int C=512,W=16; long sn=256L*C, sh=16L*C, sw=C;
+    hipLaunchKernelGGL(corr_lab_kernel<0>, dim3(B*R), dim3(256), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+    CK(hipDeviceSynchronize()); CK(hipMemcpy(o1.data(),out+(size_t)1000*P*P,n*4,hipMemcpyDeviceToHost));
+    CK(hipMemset(out,0xff,(size_t)B*R*P*P*4));
+    hipLaunchKernelGGL(corr_v5_kernel<0>, dim3(B*R), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+    CK(hipDeviceSynchronize()); CK(hipMemcpy(o5.data(),out+(size_t)1000*P*P,n*4,hipMemcpyDeviceToHost));
+    double md=0, mx=0; for(size_t i=0;i<n;++i){ double d=fabs((double)o1[i]-o5[i]); if(!(d<=md)) md=d; if(fabs(o1[i])>mx) mx=fabs(o1[i]); }
+    printf("v5 vs v1: max abs diff %.3e (max |v1| %.3e)\n", md, mx);
+  }
+  if(only==5){ t=run5<0>(ft,fr,vt,vr,out,B,R); printf("v5 full %.3f ms\n",t); return 0; }
+  if(only==0){ t=run<0>(ft,fr,vt,vr,out,B,R); printf("full %.3f ms\n",t); return 0; }
+  if(only==1){ t=run<1>(ft,fr,vt,vr,out,B,R); printf("loads %.3f ms\n",t); return 0; }
+  if(only==2){ t=run<2>(ft,fr,vt,vr,out,B,R); printf("noloads %.3f ms\n",t); return 0; }
+  t=run<0>(ft,fr,vt,vr,out,B,R); printf("full        %.3f ms  %.0f GB/s\n",t,bytes/t/1e6);
+  t=run<1>(ft,fr,vt,vr,out,B,R); printf("loads+lds   %.3f ms  %.0f GB/s\n",t,bytes/t/1e6);
+  t=run<2>(ft,fr,vt,vr,out,B,R); printf("no loads    %.3f ms\n",t);
+  t=run<3>(ft,fr,vt,vr,out,B,R); printf("no out store%.3f ms\n",t);
+  t=run3<0>(ft,fr,vt,vr,out,B,R); printf("v3 full        %.3f ms  %.0f GB/s\n",t,bytes/t/1e6);
+  t=run3<1>(ft,fr,vt,vr,out,B,R); printf("v3 loads+lds   %.3f ms  %.0f GB/s\n",t,bytes/t/1e6);
+  t=run3<2>(ft,fr,vt,vr,out,B,R); printf("v3 no loads    %.3f ms\n",t);
+  t=run3<3>(ft,fr,vt,vr,out,B,R); printf("v3 no out store%.3f ms\n",t);
+  t=run5<0>(ft,fr,vt,vr,out,B,R); printf("v5 full        %.3f ms  %.0f GB/s\n",t,bytes/t/1e6);
+  t=run5<1>(ft,fr,vt,vr,out,B,R); printf("v5 loads+lds   %.3f ms  %.0f GB/s\n",t,bytes/t/1e6);
+  t=run5<2>(ft,fr,vt,vr,out,B,R); printf("v5 no loads    %.3f ms\n",t);
+  t=run5<3>(ft,fr,vt,vr,out,B,R); printf("v5 no out store%.3f ms\n",t);
+  CK(hipDeviceSynchronize());
+  return 0;
+}
