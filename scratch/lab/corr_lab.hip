@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256, 1) void corr_lab_kernel(const float* ft, long 
 #include "corr_v3.h"
 #include "corr_v4.h"
 #include "corr_v5.h"
+#include "corr_v6.h"
+#include "corr_v7.h"
 }
 
 #include <cstdio>
@@ -158,13 +160,33 @@ template <int MODE> float run3(const float* ft,const float* fr,const float* vt,c
   hipEventRecord(e1,0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms,e0,e1); return ms/n;
 }
-template <int MODE> float run5(const float* ft,const float* fr,const float* vt,const float* vr,float* out,int B,int R){
+template <int MODE, int PRIO = 0> float run5(const float* ft,const float* fr,const float* vt,const float* vr,float* out,int B,int R){
   const int C=512,W=16; long sn=256L*C, sh=16L*C, sw=C;
   hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for(int i=0;i<2;++i) hipLaunchKernelGGL(corr_v5_kernel<MODE>, dim3(B*R), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  for(int i=0;i<2;++i) hipLaunchKernelGGL((corr_v5_kernel<MODE, PRIO>), dim3(B*R), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
   hipEventRecord(e0,0);
   const int n=5;
-  for(int i=0;i<n;++i) hipLaunchKernelGGL(corr_v5_kernel<MODE>, dim3(B*R), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  for(int i=0;i<n;++i) hipLaunchKernelGGL((corr_v5_kernel<MODE, PRIO>), dim3(B*R), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  hipEventRecord(e1,0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms,e0,e1); return ms/n;
+}
+template <int MODE, int PRIO = 0> float run7(const float* ft,const float* fr,const float* vt,const float* vr,float* out,int B,int R){
+  const int C=512,W=16; long sn=256L*C, sh=16L*C, sw=C;
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for(int i=0;i<2;++i) hipLaunchKernelGGL((corr_v7_kernel<MODE, PRIO>), dim3(B*R), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  hipEventRecord(e0,0);
+  const int n=5;
+  for(int i=0;i<n;++i) hipLaunchKernelGGL((corr_v7_kernel<MODE, PRIO>), dim3(B*R), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+  hipEventRecord(e1,0); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms,e0,e1); return ms/n;
+}
+template <int MODE> float run6(const float* ft,const float* fr,const float* vt,const float* vr,float* out,int B,int R,int NB=256){
+  const int C=512,W=16; long sn=256L*C, sh=16L*C, sw=C;
+  hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for(int i=0;i<2;++i) hipLaunchKernelGGL(corr_v6_kernel<MODE>, dim3(NB), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out, B*R);
+  hipEventRecord(e0,0);
+  const int n=5;
+  for(int i=0;i<n;++i) hipLaunchKernelGGL(corr_v6_kernel<MODE>, dim3(NB), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out, B*R);
   hipEventRecord(e1,0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms,e0,e1); return ms/n;
 }
@@ -199,6 +221,22 @@ int main(int argc,char**argv){ int only = argc>1 ? atoi(argv[1]) : -1;
     CK(hipDeviceSynchronize()); CK(hipMemcpy(o5.data(),out+(size_t)1000*P*P,n*4,hipMemcpyDeviceToHost));
     double md=0, mx=0; for(size_t i=0;i<n;++i){ double d=fabs((double)o1[i]-o5[i]); if(!(d<=md)) md=d; if(fabs(o1[i])>mx) mx=fabs(o1[i]); }
     printf("v5 vs v1: max abs diff %.3e (max |v1| %.3e)\n", md, mx);
+    CK(hipMemset(out,0xff,(size_t)B*R*P*P*4));
+    hipLaunchKernelGGL(corr_v6_kernel<0>, dim3(256), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out, B*R);
+    CK(hipDeviceSynchronize()); CK(hipMemcpy(o5.data(),out+(size_t)1000*P*P,n*4,hipMemcpyDeviceToHost));
+    md=0; for(size_t i=0;i<n;++i){ double d=fabs((double)o1[i]-o5[i]); if(!(d<=md)) md=d; }
+    printf("v6 vs v1: max abs diff %.3e\n", md);
+    CK(hipMemset(out,0xff,(size_t)B*R*P*P*4));
+    hipLaunchKernelGGL((corr_v7_kernel<0,0>), dim3(B*R), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out);
+    CK(hipDeviceSynchronize()); CK(hipMemcpy(o5.data(),out+(size_t)1000*P*P,n*4,hipMemcpyDeviceToHost));
+    md=0; for(size_t i=0;i<n;++i){ double d=fabs((double)o1[i]-o5[i]); if(!(d<=md)) md=d; }
+    printf("v7 vs v1: max abs diff %.3e\n", md);
+    // ragged: 2045 pairs over 256 blocks
+    CK(hipMemset(out,0xff,(size_t)B*R*P*P*4));
+    hipLaunchKernelGGL(corr_v6_kernel<0>, dim3(256), dim3(512), 0, 0, ft,sn,sh,sw, fr,sn,sh,sw, W, C, vt, vr, R, out, B*R-3);
+    CK(hipDeviceSynchronize()); CK(hipMemcpy(o5.data(),out+(size_t)1000*P*P,n*4,hipMemcpyDeviceToHost));
+    md=0; for(size_t i=0;i<n;++i){ double d=fabs((double)o1[i]-o5[i]); if(!(d<=md)) md=d; }
+    printf("v6 ragged vs v1: max abs diff %.3e\n", md);
   }
   if(only==5){ t=run5<0>(ft,fr,vt,vr,out,B,R); printf("v5 full %.3f ms\n",t); return 0; }
   if(only==0){ t=run<0>(ft,fr,vt,vr,out,B,R); printf("full %.3f ms\n",t); return 0; }
@@ -216,6 +254,19 @@ int main(int argc,char**argv){ int only = argc>1 ? atoi(argv[1]) : -1;
   t=run5<1>(ft,fr,vt,vr,out,B,R); printf("v5 loads+lds   %.3f ms  %.0f GB/s\n",t,bytes/t/1e6);
   t=run5<2>(ft,fr,vt,vr,out,B,R); printf("v5 no loads    %.3f ms\n",t);
   t=run5<3>(ft,fr,vt,vr,out,B,R); printf("v5 no out store%.3f ms\n",t);
+  t=run5<4>(ft,fr,vt,vr,out,B,R); printf("v5 no split/store %.3f ms\n",t);
+  t=run5<0,1>(ft,fr,vt,vr,out,B,R); printf("v5 full prio    %.3f ms  %.0f GB/s\n",t,bytes/t/1e6);
+  t=run5<2,1>(ft,fr,vt,vr,out,B,R); printf("v5 noloads prio %.3f ms\n",t);
+  t=run7<0>(ft,fr,vt,vr,out,B,R); printf("v7 full        %.3f ms  %.0f GB/s\n",t,bytes/t/1e6);
+  t=run7<1>(ft,fr,vt,vr,out,B,R); printf("v7 loads+lds   %.3f ms\n",t);
+  t=run7<2>(ft,fr,vt,vr,out,B,R); printf("v7 no loads    %.3f ms\n",t);
+  t=run7<3>(ft,fr,vt,vr,out,B,R); printf("v7 no out store%.3f ms\n",t);
+  t=run7<4>(ft,fr,vt,vr,out,B,R); printf("v7 no split/store %.3f ms\n",t);
+  t=run6<0>(ft,fr,vt,vr,out,B,R); printf("v6 full        %.3f ms  %.0f GB/s\n",t,bytes/t/1e6);
+  t=run6<0>(ft,fr,vt,vr,out,B,R,512); printf("v6 full g512   %.3f ms  %.0f GB/s\n",t,bytes/t/1e6);
+  t=run6<1>(ft,fr,vt,vr,out,B,R); printf("v6 loads+lds   %.3f ms  %.0f GB/s\n",t,bytes/t/1e6);
+  t=run6<2>(ft,fr,vt,vr,out,B,R); printf("v6 no loads    %.3f ms\n",t);
+  t=run6<3>(ft,fr,vt,vr,out,B,R); printf("v6 no out store%.3f ms\n",t);
   CK(hipDeviceSynchronize());
   return 0;
 }

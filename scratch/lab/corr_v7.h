@@ -2,7 +2,7 @@
 // runs the MFMAs of chunk k, the other splits + stores its share of chunk k+1 into the second
 // LDS image; then the roles swap.  Two prefetch register sets keep loads in flight all the time.
 template <int MODE, int PRIO = 0>
-__global__ __launch_bounds__(512, 1) void corr_v5_kernel(const float* ft, long tsn, long tsh, long tsw,
+__global__ __launch_bounds__(512, 1) void corr_v7_kernel(const float* ft, long tsn, long tsh, long tsw,
                                                          const float* fr, long rsn, long rsh, long rsw, int W,
                                                          int C, const float* vt, const float* vr, int R,
                                                          float* out) {
@@ -92,35 +92,30 @@ __global__ __launch_bounds__(512, 1) void corr_v5_kernel(const float* ft, long t
   // channel offset of chunk c (rotated start); past the last chunk: beyond the descriptor's
   // range, where a buffer load returns zeros without touching memory
   auto choff = [&](int c) { int q = c + c_start; q = q >= nchunk ? q - nchunk : q; return c < nchunk ? q * CKC : (1 << 28); };
-  // Group g keeps chunk c in register set (c + g) & 1 and runs one phase behind/ahead of the
-  // other group:   g0: C0 | S1 | C1 | S2 | ...      g1: S1 | C0 | S2 | C1 | ...
-  // (Ck = MFMAs of chunk k from image k&1, Sk = split+store of the group's share of chunk k)
-  load(rt[0], rr[0], choff(g));
-  load(rt[1], rr[1], choff(1 - g));
-  if (g == 0) { store(rt[0], rr[0], 0); load(rt[0], rr[0], choff(2)); }
-  else        { store(rt[1], rr[1], 0); load(rt[1], rr[1], choff(2)); }
+  // One barrier per chunk.  In round k every wave runs the MFMAs of chunk k (image k&1) and
+  // stores its share of chunk k+1 (register set (k+1)&1) into the other image: group 1 BEFORE
+  // its MFMAs, group 0 AFTER them, so on each SIMD one wave's split runs under the other's MFMAs.
+  load(rt[0], rr[0], choff(0));
+  load(rt[1], rr[1], choff(1));
+  store(rt[0], rr[0], 0);
+  load(rt[0], rr[0], choff(2));
   __syncthreads();
-  if (g == 1) {
-    store(rt[0], rr[0], 1);
-    load(rt[0], rr[0], choff(3));
-    __syncthreads();
-  }
   for (int k = 0; k < nchunk; k += 2) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int cs = k + h + 1 + g;        // chunk this group stores in this step (register set h^1)
-      if (PRIO) __builtin_amdgcn_s_setprio(1);
-      if (MODE != 1) compute(h);
-      if (PRIO) __builtin_amdgcn_s_setprio(0);
-      __syncthreads();
-      if (cs < nchunk && MODE != 4) {
-        store(rt[h ^ 1], rr[h ^ 1], (h ^ 1) ^ g);
+      const bool st = k + h + 1 < nchunk && MODE != 4;
+      if (g == 1) {
+        if (st) store(rt[h ^ 1], rr[h ^ 1], h ^ 1);
+        if (MODE != 2) load(rt[h ^ 1], rr[h ^ 1], choff(k + h + 3));
       }
-      if (MODE != 2) load(rt[h ^ 1], rr[h ^ 1], choff(cs + 2));
+      if (MODE != 1) compute(h);
+      if (g == 0) {
+        if (st) store(rt[h ^ 1], rr[h ^ 1], h ^ 1);
+        if (MODE != 2) load(rt[h ^ 1], rr[h ^ 1], choff(k + h + 3));
+      }
       __syncthreads();
     }
   }
-  if (g == 0) __syncthreads();
   float* nT = reinterpret_cast<float*>(sm);
   float* nR = nT + P;
 #pragma unroll
