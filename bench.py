@@ -65,9 +65,13 @@ def timed_steps(step_fn, steps, warmup, world):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    verbose = os.environ.get('MT355_BENCH_VERBOSE') == '1'
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
         step_fn()
+        if verbose:     # (perturbs the measurement: debugging aid only)
+            torch.cuda.synchronize()
+            print(f'[rank {os.environ.get("RANK", "0")}] step {i}: {time.perf_counter() - t0:.3f} s', file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -169,11 +173,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # MT355_BENCH_BACKEND=gloo rehearses the N > 1 code path with several ranks on ONE card
+    # (ranks share device local % device_count; gloo stages CUDA tensors through the host)
+    backend = os.environ.get('MT355_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     import master_thesis_amd as mt
     from master_thesis_amd import dist as mdist
     from master_thesis_amd.synthetic import make_batch
@@ -205,10 +217,19 @@ def main():
         gstep = GraphedTrainStep(dfpn, opt, batch, include_optimizer=(world == 1))
 
         def dfpn_step():   # noqa: F811
+            verbose = os.environ.get('MT355_BENCH_VERBOSE') == '1'
+            t0 = time.perf_counter()
             loss = gstep.step()
+            if verbose:
+                torch.cuda.synchronize(); t1 = time.perf_counter()
             if world > 1:
                 mdist.sync_gradients(opt)
+                if verbose:
+                    torch.cuda.synchronize(); t2 = time.perf_counter()
                 opt.step()
+                if verbose:
+                    torch.cuda.synchronize()
+                    print(f'  replay {t1 - t0:.3f} allreduce {t2 - t1:.3f} adam {time.perf_counter() - t2:.3f}', file=sys.stderr, flush=True)
             return loss
 
     dt = timed_steps(dfpn_step, args.steps, args.warmup, world)

@@ -32,6 +32,12 @@ def sync_gradients(optimizer):
     if not is_dist():
         optimizer.grad_scale = 1.0
         return
+    # The backward (or the replayed step graph) is drained first: the collective then starts
+    # on an idle queue instead of being ordered behind ~1.6 k queued launches through a
+    # cross-stream event (with gloo on CUDA tensors that wait was observed to take seconds).
+    # Cost: one host wake-up per step (tens of microseconds against a ~200 ms step).
+    if optimizer.flat_g.is_cuda:
+        torch.cuda.current_stream().synchronize()
     allreduce_flat_(optimizer.flat_g)
     optimizer.grad_scale = 1.0 / dist.get_world_size()
 

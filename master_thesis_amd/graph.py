@@ -31,6 +31,10 @@ class GraphedTrainStep:
         # graph would carry AccumulateGrad nodes bound to the side stream
         import gc
         gc.collect()
+        # the weight packs must be part of the captured step (without the optimizer in the
+        # graph nothing invalidated the packs the warm-up steps cached)
+        from . import engine as E
+        E.bump_weight_epoch()
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad()
         with torch.cuda.graph(self.graph):
