@@ -172,6 +172,36 @@ def test_correlation(mt, golden):
         assert_close(M.correlation_masked_4d(ft, None, fr, None), torch.from_numpy(g[f'{tag}.unmasked']), what=tag)
 
 
+def test_correlation_properties_at_scale(mt):
+    """Size-independent properties of the fused correlation kernel on many pairs
+    (ragged pair count for the XCD tile map): a frame correlated with itself has
+    a unit diagonal where visible and a symmetric volume, |cosine| <= 1, masked
+    positions are exactly 0; and agreement with a plain fp32 torch evaluation."""
+    from master_thesis_amd import ops
+    b, r, p, c = 37, 3, 256, 512
+    gen = torch.Generator(device='cpu').manual_seed(7)
+    ft = torch.randn((b, 16, 16, c), generator=gen).to(dev())
+    fr = torch.randn((b * r, 16, 16, c), generator=gen).to(dev())
+    fr[0::r] = ft                                             # reference 0 of every clip = the target itself
+    vt = (torch.rand((b, p), generator=gen) > 0.2).float().to(dev())
+    vr = (torch.rand((b * r, p), generator=gen) > 0.2).float().to(dev())
+    vr[0::r] = vt
+    out = ops.correlation(ft, fr, vt, vr, b, r).view(b, r, p, p)
+    self_c = out[:, 0]
+    diag = torch.diagonal(self_c, dim1=1, dim2=2)
+    assert float((diag - vt).abs().max()) < 2e-5               # 1 where visible, 0 where masked
+    assert float((self_c - self_c.transpose(1, 2)).abs().max()) < 2e-5
+    assert float(out.abs().max()) <= 1.0 + 2e-5
+    assert float((out * (1 - vt)[:, None, :, None]).abs().max()) == 0.0
+    assert float((out * (1 - vr.view(b, r, p))[:, :, None, :]).abs().max()) == 0.0
+    tn = ft.view(b, p, c) * vt[..., None]
+    tn = tn / (tn.norm(dim=2, keepdim=True) + 1e-9)
+    rn = fr.view(b, r, p, c) * vr.view(b, r, p, 1)
+    rn = rn / (rn.norm(dim=3, keepdim=True) + 1e-9)
+    ref = torch.einsum('bpc,brqc->brpq', tn.double(), rn.double()).float()
+    assert float((out - ref).abs().max()) < 2e-5
+
+
 def _np_warp_indices(grid, h, w):
     """numpy restatement of grid_sample's index arithmetic (align_corners=True):
     ix = ((g+1)/2)*(W-1); corner = floor; nearest = rint (ties to even)."""

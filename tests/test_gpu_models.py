@@ -280,6 +280,29 @@ def test_graphed_step_matches_eager(mt, dfpn_sd):
     assert float((ge - gg).norm() / ge.norm()) < 1e-4
 
 
+def test_graph_without_optimizer_sees_weight_updates(mt, dfpn_sd):
+    """The N > 1 arrangement: forward + backward replayed from the graph, the
+    all-reduce and Adam launched after it.  The replay must re-pack the weights
+    the eager Adam just changed (the packs are captured nodes, not cached
+    tensors): after an update the replayed loss equals an eager evaluation of
+    the updated model."""
+    from master_thesis_amd.graph import GraphedTrainStep
+    batch = to_dev(S.synthetic_batch(1, 2, 64, 64, seed=13, flows_use=[True]))
+    model = mt.DFPN(mt.VGGFeatures(device=DEV), **KW)
+    model.load_state_dict(dfpn_sd)
+    model = model.to(DEV)
+    opt = model.configure_optimizers()['optimizer']
+    opt.param_groups[0]['lr'] = 1e-2             # a visible change per step
+    g = GraphedTrainStep(model, opt, batch, include_optimizer=False, warmup=1)
+    l0 = float(g.step())
+    opt.step()
+    l1 = float(g.step())
+    with torch.no_grad():
+        l1_eager = float(model.training_step(batch, 0))
+    assert abs(l1 - l0) > 1e-4 * abs(l0), (l0, l1)
+    np.testing.assert_allclose(l1, l1_eager, rtol=1e-5)
+
+
 def test_device_side_adam_replays(mt):
     """The capturable Adam (step counter and lr on the device) replayed from a
     graph equals torch.optim.Adam step for step."""
