@@ -127,6 +127,31 @@ def corr_roofline(b_pairs=2048):
             'tflops': flops / (ms * 1e-3) / 1e12}
 
 
+PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_final_pmc_hbm_traffic.txt')
+
+
+def pmc_traffic(label):
+    """HBM bytes per launch of the kernel ``label`` from the committed rocprofv3 PMC
+    passes (profiles/: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 correction
+    applied there); None when the profile holds no row for it.  The counters cannot be
+    collected inside this process, so this is the profile of the same workload."""
+    none = {'traffic': None}
+    try:
+        rows = open(PMC_FILE).read().splitlines()
+    except OSError:
+        return none
+    want = label.replace(',bf16', ',0').replace(',f16', ',1').replace(' ', '')
+    for row in rows:
+        if row.startswith('#') or '>' not in row:
+            continue
+        name, rest = row.rsplit('>', 1)
+        if (name + '>').replace(' ', '').startswith(want.rstrip('>')):   # (the label may omit trailing template arguments)
+            f = rest.strip(',').split(',')
+            return {'traffic': float(f[3]) * 1e6, 'traffic_unit': 'bytes/launch (PMC, (2*FETCH_SIZE+WRITE_SIZE)*1024)',
+                    'traffic_source': 'profiles/r01_final_pmc_hbm_traffic.txt', 'traffic_launches': int(f[0])}
+    return none
+
+
 def host_cores():
     """CPU cores this process may really use: affinity mask and cgroup quota."""
     n = os.cpu_count() or 1
@@ -259,7 +284,7 @@ def main():
         per = 3 if (',f16' in name or ',2,bf16' in name or name.endswith(',2>')) else (6 if 'split' in name or 'halo' in name else 1)
         peak = PEAK_FP32_MFMA_TFLOPS if per == 1 else PEAK_16BIT_MFMA_TFLOPS / per
         out['roofline'] = {'kernel': name, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                           'frac': ach / peak, 'traffic': None,
+                           'frac': ach / peak, **pmc_traffic(name),
                            'note': f'achieved = algorithmic conv FLOP / kernel time; peak = dense 16-bit MFMA peak '
                                    f'{PEAK_16BIT_MFMA_TFLOPS:.0f} TFLOP/s / {per} MFMA products per fp32 multiply-add '
                                    f'of this arithmetic (executed MFMA rate = {per} x achieved)' if per > 1 else
