@@ -44,9 +44,10 @@ enum mt_act { MT_ACT_NONE = 0, MT_ACT_RELU = 1, MT_ACT_LRELU02 = 2 };
  * MT_PREC_F16X3  2 fp16 terms (22 significant bits) of the operand scaled by a
  *                per-tensor power of two, 3 partial products on
  *                v_mfma_f32_32x32x16_f16: ~7e-8 relative per product (below the
- *                fp32 accumulation noise) at the BF16X3 cost.  Halo-tile
- *                kernels only; needs the device scalars max|X|, max|W| (or
- *                max|D|, max|G|) from mt_absmax. */
+ *                fp32 accumulation noise) at the BF16X3 cost.  Needs the
+ *                device scalars max|X|, max|W| (or max|D|, max|G|) from
+ *                mt_absmax; not available on the fp32 kernels' weight layout
+ *                (pack with mt_weight_pack_split / _halo and w_amax). */
 enum mt_precision { MT_PREC_F32 = 0, MT_PREC_BF16X3 = 1, MT_PREC_BF16X6 = 2, MT_PREC_F16X3 = 3 };
 /* Kernel selection of mt_conv_run: AUTO picks the LDS halo-tile direct
  * convolution for stride-1 3x3/5x5 "same" layers (split precisions, X.C % 8 ==
@@ -115,7 +116,7 @@ typedef struct {
   int32_t algo;       /* mt_algo */
   int32_t wt_layout;  /* mt_wt_layout */
   const float* x_amax; /* MT_PREC_F16X3: device scalar >= max|X| (mt_absmax) */
-  const float* w_amax; /* MT_PREC_F16X3: the scalar given to mt_weight_pack_halo */
+  const float* w_amax; /* MT_PREC_F16X3: the scalar given to mt_weight_pack_halo / _split */
 } mt_conv;
 
 int mt_conv_run(const mt_conv* d, void* stream);
@@ -163,15 +164,17 @@ int mt_bias_grad(const mt_view* d, float* db, int32_t C, float* ws,
 int mt_weight_pack(const float* src, int32_t A, int32_t B, int32_t T,
                    int64_t sa, int64_t sb, int64_t st, float* dst, int32_t AP,
                    int32_t BP, void* stream);
-/* same selection, split into bf16 planes for the split precisions:
- * dst = [NS][AP][Kp] bf16 (plane s = s-th term; NS = 2 for BF16X3, 3 for
- * BF16X6), Kp = T*BP rounded up to a multiple of 32.  flip = 1 reverses the
- * tap order (t -> T-1-t): with a and b swapped this turns the backward-data of
- * a stride-1 "same" convolution into a plain forward convolution. */
+/* same selection, split into 16-bit planes for the split precisions:
+ * dst = [NS][AP][Kp] (plane s = s-th term; NS = 2 bf16 planes for BF16X3, 3 for
+ * BF16X6, 2 fp16 planes of W * 2^k for F16X3), Kp = T*BP rounded up to a
+ * multiple of 32.  flip = 1 reverses the tap order (t -> T-1-t): with a and b
+ * swapped this turns the backward-data of a stride-1 "same" convolution into a
+ * plain forward convolution.  w_amax: device scalar >= max|W| (mt_absmax_flat)
+ * for F16X3, NULL otherwise. */
 int mt_weight_pack_split(const float* src, int32_t A, int32_t B, int32_t T,
                          int64_t sa, int64_t sb, int64_t st, void* dst,
                          int32_t AP, int32_t BP, int32_t precision, int32_t flip,
-                         void* stream);
+                         const float* w_amax, void* stream);
 /* Weight tiles of the halo-tile kernel: dst = [tap][chunk][ntile][plane][BN][CK+8]
  * bf16, every tile the exact LDS image the kernel copies (CK = 32 / 16 input
  * channels per chunk for BF16X3 / BF16X6, BN = 128 / 64 / 32 by AP). */

@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvK p) {
 // Weights are split once at pack time; activations are split while they are
 // staged into LDS.  K per LDS stage: BKT = 32 (NS = 2) or 16 (NS = 3) so that
 // both fit two blocks per CU.
-template <int WGM, int WGN, int TM, int TN, int NS, bool PAR>
+// FMT = 1 ("f16x3", NS = 2): fp16 terms of operands scaled by per-tensor powers
+// of two (see conv_common.h); the accumulators are unscaled before the epilogue.
+template <int WGM, int WGN, int TM, int TN, int NS, bool PAR, int FMT = 0>
 __global__ __launch_bounds__(256) void igemm_split_kernel(ConvK p) {
   constexpr int BKT = NS == 3 ? 16 : 32;            // k per LDS stage
   constexpr int LD = BKT + 8;                       // bf16 per LDS row (+16 B pad: conflict-free b128 reads)
@@ -172,6 +174,8 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(ConvK p) {
   const int wm = wave / WGN, wn = wave % WGN;
   const int li = lane & 31, lh = lane >> 5;
   const int m0 = xcd_remap(blockIdx.x, gridDim.x) * BM, n0 = blockIdx.y * BN;
+  const float scA = FMT ? pow2_scale(*p.xamax) : 1.f;
+  const float inv = FMT ? 1.f / (scA * pow2_scale(*p.wamax)) : 1.f;
 
   // PAR: a stride-2 transposed gather (conv backward-data / conv_transpose
   // forward) only touches taps with kh == (oy + pad) mod 2: instead of
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(ConvK p) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       bf16x4 parts[NS];
-      split4<NS>(ra[i], parts);
+      split4f<NS, FMT>(ra[i], scA, parts);
 #pragma unroll
       for (int s = 0; s < NS; ++s)
         *reinterpret_cast<bf16x4*>(&sA[buf][s][(row0 + RPP * i) * LD + col4 * 4]) = parts[s];
@@ -321,10 +325,18 @@ __global__ __launch_bounds__(256) void igemm_split_kernel(ConvK p) {
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) mfma_split<NS>(fa[a], fb[b], acc[a][b]);
+        for (int b = 0; b < TN; ++b) mfma_splitf<NS, FMT>(fa[a], fb[b], acc[a][b]);
     }
     if (kt + 1 < nk) store_tile(buf ^ 1);
     __syncthreads();
+  }
+  if (FMT) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] *= inv;
   }
   igemm_epilogue_map<TM, TN>(p, pm, acc, m0, n0, wm, wn, li, lh);
 }
@@ -375,10 +387,12 @@ void launch_igemm(const ConvK& k, hipStream_t s, int prec = MT_PREC_F32) {
     const int mc = k.N * ((k.Ho + 1) / 2) * ((k.Wo + 1) / 2);
     dim3 g4((mc + BM - 1) / BM, (k.Co + BN - 1) / BN, 4);
     if (prec == MT_PREC_BF16X3) hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 2, true>), g4, dim3(256), 0, s, k);
+    else if (prec == MT_PREC_F16X3) hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 2, true, 1>), g4, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 3, true>), g4, dim3(256), 0, s, k);
     return;
   }
   if (prec == MT_PREC_BF16X3) hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 2, false>), grid, dim3(256), 0, s, k);
+  else if (prec == MT_PREC_F16X3) hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 2, false, 1>), grid, dim3(256), 0, s, k);
   else if (prec == MT_PREC_BF16X6) hipLaunchKernelGGL((igemm_split_kernel<WGM, WGN, TM, TN, 3, false>), grid, dim3(256), 0, s, k);
   else hipLaunchKernelGGL((igemm_kernel<WGM, WGN, TM, TN>), grid, dim3(256), 0, s, k);
 }
@@ -504,7 +518,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgK p) {
 // 4-channel group) -> two 16-B loads, and per channel and plane ONE 32-bit LDS
 // store of the two neighbouring pixels, into [channel][pixel] tiles that the
 // MFMA operands then read along k with ds_read_b128.
-template <int WGM, int WGN, int TM, int TN, int NS>
+template <int WGM, int WGN, int TM, int TN, int NS, int FMT = 0>
 __global__ __launch_bounds__(256) void wgrad_split_kernel(WgK p) {
   constexpr int BKT = NS == 3 ? 16 : 32;                        // pixels per LDS stage
   constexpr int LD = BKT + 8, PPN = BKT / 2;                    // pixel pairs per stage
@@ -527,6 +541,8 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgK p) {
   const int pend = min(p.M, pbeg + p.per_split);
   const int HWd = p.Hd * p.Wd;
   const int HL = p.Hg << p.ups, WL = p.Wg << p.ups;
+  const float scD = FMT ? pow2_scale(*p.damax) : 1.f, scG = FMT ? pow2_scale(*p.gamax) : 1.f;
+  const float inv = FMT ? 1.f / (scD * scG) : 1.f;
 
   f32x4 rd[RA][2], rg[RB][2];
   auto load_chunk = [&](int pix0) {
@@ -571,8 +587,8 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgK p) {
       const int t = tid + 256 * i, pp = t % PPN, cg = t / PPN;
       if (t < TA) {
         bf16x4 p0[NS], p1[NS];
-        split4<NS>(rd[i][0], p0);
-        split4<NS>(rd[i][1], p1);
+        split4f<NS, FMT>(rd[i][0], scD, p0);
+        split4f<NS, FMT>(rd[i][1], scD, p1);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -587,8 +603,8 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgK p) {
       const int t = tid + 256 * i, pp = t % PPN, cg = t / PPN;
       if (t < TB) {
         bf16x4 p0[NS], p1[NS];
-        split4<NS>(rg[i][0], p0);
-        split4<NS>(rg[i][1], p1);
+        split4f<NS, FMT>(rg[i][0], scG, p0);
+        split4f<NS, FMT>(rg[i][1], scG, p1);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -635,7 +651,7 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgK p) {
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) mfma_split<NS>(fa[a], fb[b], acc[a][b]);
+        for (int b = 0; b < TN; ++b) mfma_splitf<NS, FMT>(fa[a], fb[b], acc[a][b]);
     }
     if (ch + 1 < nchunks) store_chunk(buf ^ 1);
     __syncthreads();
@@ -651,7 +667,7 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgK p) {
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         const int bi = b0 + wn * TN * 32 + b * 32 + li;
-        if (bi < p.Cg) slab[((long)ai * T + tap) * p.Cg + bi] = acc[a][b][r];
+        if (bi < p.Cg) slab[((long)ai * T + tap) * p.Cg + bi] = acc[a][b][r] * inv;
       }
     }
 }
@@ -659,8 +675,9 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgK p) {
 // packed weights for the split paths: dst[plane][a][Kp], plane s = s-th bf16
 // term, Kp = row length padded to a multiple of 32 with zeros
 __global__ void weight_pack_split_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
-                                         int AP, int BP, int Kp, int NS, int flip) {
+                                         int AP, int BP, int Kp, int NS, int flip, const float* wamax) {
   const long total = (long)AP * Kp;
+  const float sc = wamax ? pow2_scale(*wamax) : 1.f;    // F16X3: fp16 planes of W * 2^k
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int k = (int)(e % Kp);
     const int a = (int)(e / Kp);
@@ -668,6 +685,13 @@ __global__ void weight_pack_split_kernel(const float* src, int A, int B, int T, 
     if (k < T * BP) {
       const int t = k / BP, b = k - t * BP;
       if (a < A && b < B) v = src[a * sa + b * sb + (flip ? T - 1 - t : t) * st];
+    }
+    if (wamax) {
+      v *= sc;
+      const _Float16 h = (_Float16)v;
+      dst[e] = __builtin_bit_cast(__bf16, h);
+      dst[total + e] = __builtin_bit_cast(__bf16, (_Float16)(v - (float)h));
+      continue;
     }
     for (int s = 0; s < NS; ++s) {
       const __bf16 h = (__bf16)v;
@@ -791,8 +815,8 @@ extern "C" int mt_conv_run(const mt_conv* d, void* stream) {
   if (rc) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int prec = d->precision;
-  MT_REQUIRE(prec == MT_PREC_F32 || prec == MT_PREC_BF16X3 || prec == MT_PREC_BF16X6,
-             "mt_conv: precision %d is not available on the implicit-GEMM kernels (F16X3 is halo-tile only)", prec);
+  MT_REQUIRE(prec >= MT_PREC_F32 && prec <= MT_PREC_F16X3, "mt_conv: unknown precision %d", prec);
+  MT_REQUIRE(prec != MT_PREC_F16X3 || (d->x_amax && d->w_amax), "mt_conv: F16X3 needs x_amax and w_amax");
   if (prec != MT_PREC_F32) k.Kp = ((k.K + 31) / 32) * 32;
   k.par = (prec != MT_PREC_F32 && k.transposed && k.stride == 2 && (k.C & 7) == 0 && k.ups == 0) ? 1 : 0;
   if (k.Co > 64) launch_igemm<2, 2, 2, 2>(k, s, prec);        // 128 x 128
@@ -838,12 +862,13 @@ extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
   k.per_split = ((per + 31) / 32) * 32;
   MT_REQUIRE((int64_t)k.per_split * d->splits >= k.M, "mt_wgrad: split arithmetic");
   k.slabs = d->slabs;
+  k.damax = d->d_amax; k.gamax = d->g_amax;
   int cfg;
   wgrad_cfg(d, &k.atiles, &k.btiles, &cfg);
   dim3 grid(k.atiles * k.btiles * d->KH * d->KW, d->splits);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  MT_REQUIRE(d->precision >= MT_PREC_F32 && d->precision <= MT_PREC_BF16X6,
-             "mt_wgrad: precision not available on the generic kernel (F16X3 is halo-tile only)");
+  MT_REQUIRE(d->precision >= MT_PREC_F32 && d->precision <= MT_PREC_F16X3, "mt_wgrad: unknown precision");
+  MT_REQUIRE(d->precision != MT_PREC_F16X3 || (d->d_amax && d->g_amax), "mt_wgrad: F16X3 needs d_amax and g_amax");
 #define MT_WG_LAUNCH(KERN, ...)                                                                         \
   switch (cfg) {                                                                                        \
     case 0: hipLaunchKernelGGL((KERN<2, 2, 2, 2 __VA_ARGS__>), grid, dim3(256), 0, s, k); break;        \
@@ -854,6 +879,7 @@ extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
 #define MT_COMMA ,
   if (d->precision == MT_PREC_BF16X3) { MT_WG_LAUNCH(wgrad_split_kernel, MT_COMMA 2) }
   else if (d->precision == MT_PREC_BF16X6) { MT_WG_LAUNCH(wgrad_split_kernel, MT_COMMA 3) }
+  else if (d->precision == MT_PREC_F16X3) { MT_WG_LAUNCH(wgrad_split_kernel, MT_COMMA 2 MT_COMMA 1) }
   else { MT_WG_LAUNCH(wgrad_kernel) }
 #undef MT_WG_LAUNCH
 #undef MT_COMMA
@@ -1113,13 +1139,15 @@ extern "C" int mt_corr_masked(const mt_view* ft, const mt_view* fr, const float*
 
 extern "C" int mt_weight_pack_split(const float* src, int32_t A, int32_t B, int32_t T, int64_t sa, int64_t sb,
                                     int64_t st, void* dst, int32_t AP, int32_t BP, int32_t precision, int32_t flip,
-                                    void* stream) {
+                                    const float* w_amax, void* stream) {
   MT_REQUIRE(src && dst && A <= AP && B <= BP && (BP & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
              "mt_weight_pack_split: bad arguments");
-  MT_REQUIRE(precision == MT_PREC_BF16X3 || precision == MT_PREC_BF16X6, "mt_weight_pack_split: precision");
+  MT_REQUIRE(precision == MT_PREC_BF16X3 || precision == MT_PREC_BF16X6 || precision == MT_PREC_F16X3,
+             "mt_weight_pack_split: precision");
+  MT_REQUIRE((precision == MT_PREC_F16X3) == (w_amax != nullptr), "mt_weight_pack_split: w_amax goes with F16X3");
   const int Kp = ((T * BP + 31) / 32) * 32;
   hipLaunchKernelGGL(weight_pack_split_kernel, dim3(mt_grid_1d((int64_t)AP * Kp, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), src, A, B, T, (long)sa, (long)sb, (long)st,
-                     reinterpret_cast<__bf16*>(dst), AP, BP, Kp, precision == MT_PREC_BF16X6 ? 3 : 2, flip);
+                     reinterpret_cast<__bf16*>(dst), AP, BP, Kp, precision == MT_PREC_BF16X6 ? 3 : 2, flip, w_amax);
   return mt_check_launch("mt_weight_pack_split");
 }

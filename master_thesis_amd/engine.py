@@ -35,14 +35,19 @@ PRECISION_VGG = os.environ.get('MT355_PRECISION_VGG', 'bf16x3')
 PRECISION_NOGRAD = os.environ.get('MT355_PRECISION_NOGRAD', 'same')
 USE_HALO = os.environ.get('MT355_HALO', '1') != '0'   # LDS halo-tile kernel for stride-1 3x3/5x5 layers
 _PREC = {'f32': L.PREC_F32, 'bf16x3': L.PREC_BF16X3, 'bf16x6': L.PREC_BF16X6, 'f16x3': L.PREC_F16X3}
-_KTAG = {'f32': '', 'bf16x3': ',2', 'bf16x6': ',3'}
+_KTAG = {'f32': '', 'bf16x3': ',2', 'bf16x6': ',3', 'f16x3': ',2,f16'}
 _HTAG = {'bf16x3': '2,bf16', 'bf16x6': '3,bf16', 'f16x3': '2,f16'}
 
 
+# arithmetic of the layers the halo kernels do not take (strided, transposed, ups):
+# 'same' = PRECISION; 'bf16x6' keeps them on the 3-term bf16 split
+PRECISION_GENERIC = os.environ.get('MT355_PRECISION_GENERIC', 'same')
+
+
 def eff_precision(halo):
-    """Precision a launch really uses: f16x3 exists on the halo kernels only."""
-    if PRECISION == 'f16x3' and not halo:
-        return 'bf16x6'
+    """Precision a launch really uses."""
+    if PRECISION == 'f16x3' and not halo and PRECISION_GENERIC != 'same':
+        return PRECISION_GENERIC
     return PRECISION
 
 
@@ -201,11 +206,13 @@ def _pack(w, a_dim, kind, prec, flip=False, halo=False):
         L.call('mt_weight_pack_halo', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _PREC[prec],
                1 if flip else 0, L.ptr(wa), L.stream_ptr())
     elif prec != 'f32':
-        assert prec in ('bf16x3', 'bf16x6')
+        if prec == 'f16x3':
+            wa = new_amax(w.device)
+            L.call('mt_absmax_flat', L.ptr(w), w.numel(), L.ptr(wa), L.stream_ptr())
         kp = (t * cpad(b) + 31) // 32 * 32
         out = torch.empty((3 if prec == 'bf16x6' else 2, cpad(a), kp), device=w.device, dtype=torch.bfloat16)
         L.call('mt_weight_pack_split', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _PREC[prec],
-               1 if flip else 0, L.stream_ptr())
+               1 if flip else 0, L.ptr(wa), L.stream_ptr())
     else:
         out = torch.empty((cpad(a), t, cpad(b)), device=w.device, dtype=torch.float32)
         L.call('mt_weight_pack', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), L.stream_ptr())
