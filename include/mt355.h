@@ -117,6 +117,9 @@ typedef struct {
   int32_t wt_layout;  /* mt_wt_layout */
   const float* x_amax; /* MT_PREC_F16X3: device scalar >= max|X| (mt_absmax) */
   const float* w_amax; /* MT_PREC_F16X3: the scalar given to mt_weight_pack_halo / _split */
+  float* y_amax;       /* optional device scalar (>= 0): raised atomically to max|y| over the
+                          values this launch writes, so that the next layer's x_amax needs no
+                          extra pass (zero it before the first launch that feeds it) */
 } mt_conv;
 
 int mt_conv_run(const mt_conv* d, void* stream);

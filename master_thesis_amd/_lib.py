@@ -27,7 +27,7 @@ class Conv(C.Structure):
                 ('transposed', i32), ('ups', i32), ('act', i32), ('alpha', f32),
                 ('res', View), ('beta', f32), ('dsrc', View), ('dact', i32),
                 ('dact_c0', i32), ('accumulate', i32), ('precision', i32), ('algo', i32), ('wt_layout', i32),
-                ('x_amax', C.c_void_p), ('w_amax', C.c_void_p)]
+                ('x_amax', C.c_void_p), ('w_amax', C.c_void_p), ('y_amax', C.c_void_p)]
 
 
 class Wgrad(C.Structure):

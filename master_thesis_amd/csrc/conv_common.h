@@ -22,7 +22,18 @@ struct ConvK {
   int Kp;                          // split paths: padded row length of the packed weights
   int par;                         // 1: stride-2 transposed gather decomposed into 4 parity classes (blockIdx.z)
   const float* xamax; const float* wamax;   // F16X3: device scalars max|X|, max|W| (power-of-two scaling)
+  float* yamax;                              // optional: raised to max|y| over the values this launch writes
 };
+
+// Raise the device scalar *dst to at least v (v >= 0; non-negative floats order like their
+// bit patterns).  A plain read filters out almost every block: the scalar only grows, so
+// a stale copy can only cause a redundant atomic, never a lost maximum.
+__device__ __forceinline__ void raise_amax(float* dst, float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0 && v > __builtin_nontemporal_load(dst))
+    atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(v));
+}
 
 // Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Give
 // each XCD a contiguous band of pixel tiles so that the rows two neighbouring
@@ -43,6 +54,7 @@ template <int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue_map(const ConvK& p, const PixMap& pm, f32x16 (&acc)[TM][TN], int m0,
                                                    int n0, int wm, int wn, int li, int lh) {
   const int HWo = pm.Hc * pm.Wc;
+  float vmax = 0.f;
   // ---- epilogue -----------------------------------------------------------
   // C/D layout of the 32x32 tile: col (o) = lane & 31, row (pixel) =
   // (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -70,9 +82,11 @@ __device__ __forceinline__ void igemm_epilogue_map(const ConvK& p, const PixMap&
         if (p.accumulate) v += p.y[yo + o];
         if (p.ds && o >= p.dact_c0) v *= mt_dact_fn(p.ds[so + o], p.dact);
         p.y[yo + o] = v;
+        vmax = fmaxf(vmax, fabsf(v));
       }
     }
   }
+  if (p.yamax) raise_amax(p.yamax, vmax);
 }
 
 template <int TM, int TN>
@@ -205,7 +219,7 @@ inline int fill_convk(const mt_conv* d, ConvK* k) {
   k->ds = d->dsrc.p; k->dsn = d->dsrc.sn; k->dsh = d->dsrc.sh; k->dsw = d->dsrc.sw; k->dact = d->dact; k->dact_c0 = d->dact_c0;
   k->accumulate = d->accumulate;
   k->zb = 1; k->zdiv = 1; k->xz = k->wz = k->yz = 0; k->par = 0; k->Kp = 0;
-  k->xamax = d->x_amax; k->wamax = d->w_amax;
+  k->xamax = d->x_amax; k->wamax = d->w_amax; k->yamax = d->y_amax;
   return MT_OK;
 }
 

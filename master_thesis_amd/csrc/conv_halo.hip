@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
   }
 
   // ---- epilogue (same fused ops as igemm_epilogue, tile-local pixel map) ---
+  float vmax = 0.f;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -210,9 +211,11 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
         if (p.accumulate) v += p.y[yo + o];
         if (p.ds && o >= p.dact_c0) v *= mt_dact_fn(p.ds[so + o], p.dact);
         p.y[yo + o] = v;
+        vmax = fmaxf(vmax, fabsf(v));
       }
     }
   }
+  if (p.yamax) raise_amax(p.yamax, vmax);
 }
 
 template <int KS, int NS, int FMT>

@@ -155,8 +155,23 @@ def null_view():
 
 
 # ------------------------------------------------------- tensor magnitudes --
+_amax_chunk = {}          # device -> [chunk tensor, next free slot]
+AMAX_CHUNK = 512
+
+
 def new_amax(device):
-    return torch.zeros((1,), device=device, dtype=torch.float32)
+    """A zeroed device scalar (a slot of a zero-filled chunk: one fill launch per
+    AMAX_CHUNK scalars instead of one each; the slice keeps its chunk alive)."""
+    device = torch.device(device)
+    ent = _amax_chunk.get(device)
+    capturing = torch.cuda.is_current_stream_capturing() if device.type == 'cuda' else False
+    if ent is None or ent[1] >= AMAX_CHUNK or ent[2] != capturing:
+        # (a chunk allocated outside a graph capture must not be handed out inside one and vice versa)
+        ent = [torch.zeros((AMAX_CHUNK,), device=device, dtype=torch.float32), 0, capturing]
+        _amax_chunk[device] = ent
+    i = ent[1]
+    ent[1] += 1
+    return ent[0][i:i + 1]
 
 
 def absmax_into(t, amax):
@@ -262,10 +277,27 @@ def _amax_ptr(prec, explicit, view):
     return a.data_ptr(), a
 
 
-def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.0, x_amax=None):
+def _out_amax(prec, explicit, tensor):
+    """Device scalar the launch raises to max|output| (f16x3 only): the caller's
+    running scalar for windows of a shared buffer, else a fresh one remembered on
+    the output tensor so that amax_of() of the next layer finds it."""
+    if prec != 'f16x3':
+        return None, None
+    if explicit is not None:
+        return explicit.data_ptr(), explicit
+    a = new_amax(tensor.device)
+    try:
+        tensor._mt_amax = a
+    except AttributeError:
+        pass
+    return a.data_ptr(), a
+
+
+def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.0, x_amax=None, y_amax=None):
     """Run one layer forward.  xv: mt_view of the input; x_shape (N,H,W).
     ``x_amax``: device scalar >= max|x| (defaults to amax_of the view's tensor;
-    pass it for channel windows of a shared buffer)."""
+    pass it for channel windows of a shared buffer).  ``y_amax``: scalar to
+    raise to max|out| (windows of a shared buffer: the buffer's running max)."""
     n, h, w_ = x_shape
     ho, wo = spec.out_hw(h, w_)
     if out is None:
@@ -290,6 +322,7 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
     d.algo = 0 if USE_HALO else 1
     d.x_amax, keep = _amax_ptr(prec, x_amax, xv)
     d.w_amax = wa.data_ptr() if wa is not None else None
+    d.y_amax, keep_y = _out_amax(prec, y_amax, out)
     if spec.kind == 'c':
         flops = 2.0 * n * ho * wo * spec.cin * spec.cout * spec.k * spec.k
     else:
@@ -300,7 +333,7 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
 
 
 def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, accumulate=False, alpha=1.0,
-                       dz_amax=None):
+                       dz_amax=None, y_amax=None):
     """dIn = bwd-data(dZ) written through the view ``yv`` (the layer's input
     geometry), optionally gated by act'(dsrc) (the previous layer's saved
     output)."""
@@ -328,6 +361,7 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     d.algo = 0 if USE_HALO else 1
     d.x_amax, keep = _amax_ptr(prec, dz_amax, dzv)
     d.w_amax = wa.data_ptr() if wa is not None else None
+    d.y_amax, keep_y = _out_amax(prec, y_amax, yv._src)
     side = d.x if spec.kind == 'c' else yv          # the conv's output side
     flops = 2.0 * side.N * side.H * side.W * spec.cin * spec.cout * spec.k * spec.k
     with _Prof(_igemm_name(yv.C, as_fwd, prec).replace('{k}', str(spec.k)), flops):

@@ -52,10 +52,10 @@ class RRDBNetFn(torch.autograd.Function):
         f16 = E.PRECISION == 'f16x3'     # the f16x3 kernels need max|x| of every conv input
 
         def conv(key, xin, cin, cout, stride=1, act=NONE, ups=0, out=None, res=None, alpha=1.0, beta=0.0,
-                 x_amax=None):
+                 x_amax=None, y_amax=None):
             sp = E.LayerSpec('c', cin, cout, 3, stride, act, ups)
             return E.conv_forward(sp, E.view_of(xin), xin.shape[:3], P[key + '.weight'], P[key + '.bias'], out=out,
-                                  res=res, alpha=alpha, beta=beta, x_amax=x_amax)
+                                  res=res, alpha=alpha, beta=beta, x_amax=x_amax, y_amax=y_amax)
 
         # conv_first: five plain convs (two stride-2), no activation (:522-528)
         cur, first = x4, [x4]
@@ -82,17 +82,15 @@ class RRDBNetFn(torch.autograd.Function):
                 key = f'rrdb_trunk.{k}.rdb{j}.'
                 for i in range(1, 5):
                     dst = buf[..., nf + (i - 1) * gc: nf + i * gc]
+                    # (the launch itself raises the buffer's running max|.| by what it writes)
                     conv(f'{key}conv{i}', buf[..., :nf + (i - 1) * gc], nf + (i - 1) * gc, gc, act=LRELU, out=dst,
-                         x_amax=buf_amax)
-                    track(dst, buf_amax)
+                         x_amax=buf_amax, y_amax=buf_amax if f16 else None)
                 nxt, nxt_amax = new_buf(), E.new_amax(f0.device)
                 # 0.2 * conv5(cat) + x  (:623) written as the next block's x
                 conv(f'{key}conv5', buf, cw, nf, out=nxt[..., :nf], res=buf[..., :nf], alpha=0.2, beta=1.0,
-                     x_amax=buf_amax)
+                     x_amax=buf_amax, y_amax=nxt_amax if f16 else None)
                 bufs.append((buf, buf_amax))
                 buf, buf_amax = nxt, nxt_amax
-                if j < 3:
-                    track(buf[..., :nf], buf_amax)
             # 0.2 * y + x  (:585), in place in the next block's x window
             _axpby(buf[..., :nf], 0.2, rrdb_x, 1.0, buf[..., :nf])
             track(buf[..., :nf], buf_amax)
@@ -117,8 +115,11 @@ class RRDBNetFn(torch.autograd.Function):
         def spec(cin, cout, stride=1, ups=0):
             return E.LayerSpec('c', cin, cout, 3, stride, NONE, ups)
 
-        def wgrad(key, sp, dz, xin, scale=1.0, x_amax=None):
-            dw, db = E.conv_backward_weight(sp, dz, E.view_of(xin), P[key + '.weight'], scale=scale, x_amax=x_amax)
+        f16 = E.PRECISION == 'f16x3'
+
+        def wgrad(key, sp, dz, xin, scale=1.0, x_amax=None, dz_amax=None):
+            dw, db = E.conv_backward_weight(sp, dz, E.view_of(xin), P[key + '.weight'], scale=scale, x_amax=x_amax,
+                                            dz_amax=dz_amax)
             G[key + '.weight'], G[key + '.bias'] = dw, db
 
         def bdata(key, sp, dz, dx, **kw):
@@ -155,19 +156,21 @@ class RRDBNetFn(torch.autograd.Function):
             for j in (3, 2, 1):
                 key = f'rrdb_trunk.{k}.rdb{j}.'
                 buf, buf_amax = bufs[3 * k + (j - 1)]
+                # running max|.| of what this block's launches write into dbuf (it bounds every window)
+                dba = E.new_amax(dy.device) if f16 else None
                 # out = 0.2 * conv5(cat) + x  with d(out) = s_rdb * d_rdb
                 sp5 = spec(cw, nf)
                 wgrad(f'{key}conv5', sp5, d_rdb, buf, scale=0.2 * s_rdb, x_amax=buf_amax)
                 E.conv_backward_data(sp5, d_rdb, P[f'{key}conv5.weight'], E.view_of(dbuf), dsrc=buf, dact=LRELU,
-                                     dact_c0=nf + 3 * gc, alpha=0.2 * s_rdb)
+                                     dact_c0=nf + 3 * gc, alpha=0.2 * s_rdb, y_amax=dba)
                 for i in (4, 3, 2, 1):
                     cin = nf + (i - 1) * gc
                     spi = spec(cin, gc)
                     dzi = dbuf[..., cin: cin + gc]
-                    wgrad(f'{key}conv{i}', spi, dzi, buf[..., :cin], x_amax=buf_amax)
+                    wgrad(f'{key}conv{i}', spi, dzi, buf[..., :cin], x_amax=buf_amax, dz_amax=dba)
                     E.conv_backward_data(spi, dzi, P[f'{key}conv{i}.weight'], E.view_of(dbuf[..., :cin]), dsrc=buf,
                                          dact=LRELU if i > 1 else NONE, dact_c0=cin - gc if i > 1 else 0,
-                                         accumulate=True)
+                                         accumulate=True, dz_amax=dba, y_amax=dba)
                 # grad wrt the block input: dense part + residual path
                 d_in = torch.empty((n, h, w, nf), device=dy.device, dtype=torch.float32)
                 _axpby(dbuf[..., :nf], 1.0, d_rdb, s_rdb, d_in)
