@@ -194,6 +194,19 @@ def amax_of(t):
 
 
 # ------------------------------------------------------------ weight packs --
+def _weight_amax(w):
+    """max|w| on the device, once per weight and optimizer step (the forward and the
+    tap-flipped backward pack of a layer share it)."""
+    key = (w.data_ptr(), w._version, 'amax', WEIGHT_EPOCH)
+    hit = _pack_cache.get(key)
+    if hit is not None:
+        return hit[0]
+    wa = new_amax(w.device)
+    L.call('mt_absmax_flat', L.ptr(w), w.numel(), L.ptr(wa), L.stream_ptr())
+    _pack_cache[key] = (wa, w)
+    return wa
+
+
 def _pack(w, a_dim, kind, prec, flip=False, halo=False):
     """Packed copy of a conv weight for precision ``prec``: rows
     [AP][T][BP] (fp32 / bf16 planes) or, for the halo kernel, per-tile LDS
@@ -214,16 +227,14 @@ def _pack(w, a_dim, kind, prec, flip=False, halo=False):
     if halo:
         assert prec != 'f32'
         if prec == 'f16x3':
-            wa = new_amax(w.device)
-            L.call('mt_absmax_flat', L.ptr(w), w.numel(), L.ptr(wa), L.stream_ptr())
+            wa = _weight_amax(w)
         n = L.load().mt_weight_pack_halo_elems(cpad(a), cpad(b), t, _PREC[prec])
         out = torch.empty((n,), device=w.device, dtype=torch.bfloat16)
         L.call('mt_weight_pack_halo', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _PREC[prec],
                1 if flip else 0, L.ptr(wa), L.stream_ptr())
     elif prec != 'f32':
         if prec == 'f16x3':
-            wa = new_amax(w.device)
-            L.call('mt_absmax_flat', L.ptr(w), w.numel(), L.ptr(wa), L.stream_ptr())
+            wa = _weight_amax(w)
         kp = (t * cpad(b) + 31) // 32 * 32
         out = torch.empty((3 if prec == 'bf16x6' else 2, cpad(a), kp), device=w.device, dtype=torch.bfloat16)
         L.call('mt_weight_pack_split', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _PREC[prec],
@@ -240,6 +251,8 @@ def _pack(w, a_dim, kind, prec, flip=False, halo=False):
 def _pad_bias(b, n):
     if b is None:
         return None
+    if n == cpad(n) and b.is_contiguous():     # (kernels read the bias one float at a time)
+        return b                      # already a whole number of 8-channel groups: no padded copy
     key = (b.data_ptr(), b._version, 'bias', WEIGHT_EPOCH)
     hit = _pack_cache.get(key)
     if hit is not None:
