@@ -12,6 +12,7 @@
 // weight tile [BN][CK] (pre-split bf16 planes) is double-buffered through
 // registers; the next chunk's halo loads are in flight during the whole tap
 // loop.  One barrier per tap, two at a chunk boundary.
+#include <cstdlib>
 #include "conv_common.h"
 
 namespace {
@@ -218,11 +219,184 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
   if (p.yamax) raise_amax(p.yamax, vmax);
 }
 
+
+// ---- "register-B" variant for 128-wide output-channel tiles ----------------
+// Same pixel tile and halo image as igemm_halo_kernel, but the four waves of a
+// block split the 128 output channels (wave = 128 pixels x 32 channels) and
+// fetch their weight fragments STRAIGHT from global memory in MFMA operand
+// order (mt_weight_pack_halo writes them that way: one load instruction = one
+// contiguous 1 KiB, no two waves of a block read the same bytes).  The weights
+// therefore never pass through LDS: no LDS writes for B (LDS write bandwidth
+// is a third of its read bandwidth), no per-tap barrier.  The halo image is
+// double-buffered, so a block synchronises ONCE per K chunk (every k*k taps).
+// Fragment slot B[ks] is reloaded for the next tap right after the MFMAs that
+// read it have been issued.
+template <int KS, int FMT>
+__global__ __launch_bounds__(256, 2) void igemm_halo_rb_kernel(ConvK p, int tiles_y, int tiles_x) {
+  constexpr int NS = 2, CK = 32, LD = CK + 8, TH = 8, TW = 16, BN = 128, TM = 4;
+  constexpr int HW_ = TW + KS - 1, HH = TH + KS - 1, HP = HH * HW_;
+  constexpr int F4 = CK / 4, NH4 = HP * F4, RH = (NH4 + 255) / 256;
+  constexpr int T = KS * KS, KSTEPS = CK / 16;
+  constexpr int HALO_E = NS * HP * LD;                 // bf16 elements of one halo image
+  __shared__ __attribute__((aligned(16))) __bf16 sH[2 * HALO_E];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int ty0 = ty * TH, tx0 = tx * TW, n0 = blockIdx.y * BN;
+  const int HL = p.H << p.ups, WL = p.W << p.ups;
+  const float scA = FMT ? pow2_scale(*p.xamax) : 1.f;
+  const float inv = FMT ? 1.f / (scA * pow2_scale(*p.wamax)) : 1.f;
+  const float* xin = p.x + (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
+
+  long h_off[RH];
+  bool h_ok[RH];
+#pragma unroll
+  for (int i = 0; i < RH; ++i) {
+    const int idx = tid + 256 * i;
+    const int hp = idx / F4, c4 = idx % F4;
+    const int hy = hp / HW_, hx = hp - hy * HW_;
+    const int ly = ty0 - p.pad + hy, lx = tx0 - p.pad + hx;
+    h_ok[i] = idx < NH4 && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL;
+    h_off[i] = (long)(ly >> p.ups) * p.xsh + (long)(lx >> p.ups) * p.xsw + 4 * c4;
+  }
+  f32x4 rh[RH];
+  auto load_halo = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < RH; ++i) {
+      const int c4 = (tid + 256 * i) % F4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (h_ok[i] && c0 + 4 * c4 < p.C) v = *reinterpret_cast<const f32x4*>(xin + h_off[i] + c0);
+      rh[i] = v;
+    }
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RH; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < NH4) {
+        const int hp = idx / F4, c4 = idx % F4;
+        bf16x4 parts[NS];
+        split4f<NS, FMT>(rh[i], scA, parts);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          *reinterpret_cast<bf16x4*>(&sH[buf * HALO_E + s * HP * LD + hp * LD + 4 * c4]) = parts[s];
+      }
+    }
+  };
+  // weight fragments: [tap][chunk][ntile][wave][kstep][plane][lane] x 16 B
+  const bf16x8* wfr = reinterpret_cast<const bf16x8*>(p.wt);
+  const int nchunk = (p.C + CK - 1) / CK, ntile_w = (p.Co + BN - 1) / BN;
+  bf16x8 fb[KSTEPS][NS];
+  auto load_B = [&](int ch, int tap, int ks) {
+    const bf16x8* f = wfr + ((((long)tap * nchunk + ch) * ntile_w + blockIdx.y) * 4 + wn) * (KSTEPS * NS * 64) +
+                      ks * NS * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) fb[ks][s] = f[s * 64];
+  };
+
+  f32x16 acc[TM][1];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][0][r] = 0.f;
+
+  // MFMA row -> tile pixel map as in igemm_halo_kernel (conflict-free ds_read_b128)
+  const int apx = li < 16 ? li : ((li - HW_) & 15);
+  int a_base[TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) a_base[a] = ((2 * a + (li >> 4)) * HW_ + apx) * LD + 8 * lh;
+
+  load_halo(0);
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) load_B(0, 0, ks);
+  store_halo(0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int cur = ch & 1;
+    const bool more = ch + 1 < nchunk;
+    const __bf16* hb = sH + cur * HALO_E;
+    int kh = 0, kw = 0;
+    for (int tap = 0; tap < T; ++tap) {
+      const bool last = tap == T - 1;
+      // the next chunk's halo: converted into the other image under the last tap's MFMAs
+      if (last && more) store_halo(cur ^ 1);
+      const int toff = (kh * HW_ + kw) * LD;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        bf16x8 fa[TM][NS];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+            fa[a][s] = *reinterpret_cast<const bf16x8*>(&hb[s * HP * LD + a_base[a] + toff + ks * 16]);
+#pragma unroll
+        for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(fa[a], fb[ks], acc[a][0]);
+        // this slot's next contents: the same k-step of the next tap
+        if (!last) load_B(ch, tap + 1, ks);
+        else if (more) load_B(ch + 1, 0, ks);
+      }
+      // issued late in the chunk and after the weight loads of the next tap, so only the
+      // last tap's weight wait is ordered behind these loads
+      if (tap == T - 3 && more) load_halo((ch + 1) * CK);
+      if (++kw == KS) { kw = 0; ++kh; }
+    }
+    if (more) __syncthreads();      // the other image is complete, nobody reads this one any more
+  }
+
+  // ---- epilogue (as igemm_halo_kernel: wave = pixels 0..127 x channels wn*32..+31) ---
+  float vmax = 0.f;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int i32 = row & 31;
+      const int oy = ty0 + (row >> 4), ox = tx0 + (i32 < 16 ? i32 : ((i32 - HW_) & 15));
+      if (oy >= p.Ho || ox >= p.Wo) continue;
+      const long yo = (long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + (long)oy * p.ysh + (long)ox * p.ysw;
+      const long ro = p.res ? (long)n * p.rsn + (long)oy * p.rsh + (long)ox * p.rsw : 0;
+      const long so = p.ds ? (long)n * p.dsn + (long)oy * p.dsh + (long)ox * p.dsw : 0;
+      const int o = n0 + wn * 32 + li;
+      if (o >= p.Co) continue;
+      float v = acc[a][0][r] * inv;
+      if (p.bias) v += p.bias[o];
+      v = mt_act_fn(v, p.act) * p.alpha;
+      if (p.res) v += p.beta * p.res[ro + o];
+      if (p.accumulate) v += p.y[yo + o];
+      if (p.ds && o >= p.dact_c0) v *= mt_dact_fn(p.ds[so + o], p.dact);
+      p.y[yo + o] = v;
+      vmax = fmaxf(vmax, fabsf(v));
+    }
+  }
+  if (p.yamax) raise_amax(p.yamax, vmax);
+}
+
+// The register-B kernel is used for 128-wide output tiles with at least two K chunks (with a
+// single chunk -- the 32-channel gradients of the dense blocks -- its exposed first weight
+// fetch costs more than the barriers it saves).  The pack routine applies the same rule.
+// MT355_HALO_RB=0 keeps the LDS-staged weight tiles everywhere (A/B switch).
+bool halo_rb_wanted(int cin_p) {
+  static const bool on = [] { const char* e = getenv("MT355_HALO_RB"); return !(e && e[0] == '0'); }();
+  return on && cin_p > 32;
+}
+
 template <int KS, int NS, int FMT>
 void launch_halo(const ConvK& k, hipStream_t s) {
   const int tiles_y = (k.Ho + 7) / 8, tiles_x = (k.Wo + 15) / 16;
   const unsigned nt = (unsigned)k.N * tiles_y * tiles_x;
   if (k.Co > 64) {
+    if constexpr (NS == 2) {
+      if (halo_rb_wanted(k.C)) {
+        hipLaunchKernelGGL((igemm_halo_rb_kernel<KS, FMT>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, tiles_y,
+                           tiles_x);
+        return;
+      }
+    }
     hipLaunchKernelGGL((igemm_halo_kernel<KS, NS, FMT, 2, 2, 2, 2>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k,
                        tiles_y, tiles_x);
   } else if (k.Co > 32) {
@@ -507,6 +681,35 @@ __global__ void weight_pack_halo_kernel(const float* src, int A, int B, int T, l
     }
   }
 }
+
+// Fragment-order weights of igemm_halo_rb_kernel: dst[tap][chunk][ntile][wave 4][kstep 2][plane 2][lane 64][8]:
+// lane (li = lane & 31, lh = lane >> 5) holds W[a = ntile*128 + wave*32 + li][b = chunk*32 + kstep*16 + 8*lh + j]
+__global__ void weight_pack_halo_rb_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
+                                           int nchunk, int ntile, int flip, const float* wamax) {
+  const float sc = wamax ? pow2_scale(*wamax) : 1.f;
+  const long total = (long)T * nchunk * ntile * 4 * 2 * 64 * 8;      // elements per plane
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), ks = (int)((e >> 9) & 1), wv = (int)((e >> 10) & 3);
+    long r = e >> 12;
+    const int nt = (int)(r % ntile); r /= ntile;
+    const int ch = (int)(r % nchunk);
+    const int t = (int)(r / nchunk);
+    const int a = nt * 128 + wv * 32 + (lane & 31), b = ch * 32 + ks * 16 + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (a < A && b < B) v = src[a * sa + b * sb + (flip ? T - 1 - t : t) * st];
+    __bf16* o = dst + ((((((long)t * nchunk + ch) * ntile + nt) * 4 + wv) * 2 + ks) * 2) * 512 + lane * 8 + j;
+    if (wamax) {
+      v *= sc;
+      const _Float16 h = (_Float16)v;
+      o[0] = __builtin_bit_cast(__bf16, h);
+      o[512] = __builtin_bit_cast(__bf16, (_Float16)(v - (float)h));
+    } else {
+      const __bf16 h = (__bf16)v;
+      o[0] = h;
+      o[512] = (__bf16)(v - (float)h);
+    }
+  }
+}
 }  // namespace
 
 extern "C" int64_t mt_weight_pack_halo_elems(int32_t AP, int32_t BP, int32_t T, int32_t precision) {
@@ -526,6 +729,13 @@ extern "C" int mt_weight_pack_halo(const float* src, int32_t A, int32_t B, int32
   const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = NS == 3 ? 16 : 32;
   const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);        // the n-tile igemm_halo uses for Co = AP
   const int nchunk = (BP + CK - 1) / CK, ntile = (AP + BN - 1) / BN;
+  if (BN == 128 && NS == 2 && halo_rb_wanted(BP)) {     // fragment order for igemm_halo_rb_kernel (fits the same buffer)
+    const long tot = (long)T * nchunk * ntile * 4096;
+    hipLaunchKernelGGL(weight_pack_halo_rb_kernel, dim3(mt_grid_1d(tot, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, A, B, T, (long)sa, (long)sb, (long)st,
+                       reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, w_amax);
+    return mt_check_launch("mt_weight_pack_halo(rb)");
+  }
   const long total = (long)T * nchunk * ntile * BN * (CK + 8);
   hipLaunchKernelGGL(weight_pack_halo_kernel, dim3(mt_grid_1d(total, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), src, A, B, T, (long)sa, (long)sb, (long)st,
