@@ -127,7 +127,7 @@ def corr_roofline(b_pairs=2048):
             'tflops': flops / (ms * 1e-3) / 1e12}
 
 
-PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_final_pmc_hbm_traffic.txt')
+PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_hbm_traffic.txt')
 
 
 def pmc_traffic(label):
@@ -148,7 +148,7 @@ def pmc_traffic(label):
         if (name + '>').replace(' ', '').startswith(want.rstrip('>')):   # (the label may omit trailing template arguments)
             f = rest.strip(',').split(',')
             return {'traffic': float(f[3]) * 1e6, 'traffic_unit': 'bytes/launch (PMC, (2*FETCH_SIZE+WRITE_SIZE)*1024)',
-                    'traffic_source': 'profiles/r01_final_pmc_hbm_traffic.txt', 'traffic_launches': int(f[0])}
+                    'traffic_source': 'profiles/r01_pmc_hbm_traffic.txt', 'traffic_launches': int(f[0])}
     return none
 
 
@@ -281,7 +281,7 @@ def main():
         name, (launches, kms, kfl) = max(agg.items(), key=lambda kv: kv[1][1])
         ach = kfl / (kms * 1e-3) / 1e12
         # MFMA products issued per fp32 multiply-add by the kernel's arithmetic
-        per = 3 if (',f16' in name or ',2,bf16' in name or name.endswith(',2>')) else (6 if 'split' in name or 'halo' in name else 1)
+        per = 3 if (',f16' in name or ',2,bf16' in name or name.endswith(',2>') or '_rb_' in name) else (6 if 'split' in name or 'halo' in name else 1)
         peak = PEAK_FP32_MFMA_TFLOPS if per == 1 else PEAK_16BIT_MFMA_TFLOPS / per
         out['roofline'] = {'kernel': name, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
                            'frac': ach / peak, **pmc_traffic(name),

@@ -86,8 +86,14 @@ def halo_eligible(kind_fwd_like, stride, k, cin_p):
     return USE_HALO and PRECISION != 'f32' and kind_fwd_like and stride == 1 and k in (3, 5) and cin_p % 8 == 0
 
 
-def _igemm_name(co, halo, prec):
+HALO_RB = os.environ.get('MT355_HALO_RB', '1') != '0'     # mirrors halo_rb_wanted() in conv_halo.hip
+
+
+def _igemm_name(co, halo, prec, cin_p=0):
+    """Name of the kernel mt_conv_run picks (profiling labels only)."""
     cfg = '2,2,2,2' if co > 64 else ('2,2,2,1' if co > 32 else '4,1,1,1')
+    if halo and co > 64 and prec in ('f16x3', 'bf16x3') and cin_p > 32 and HALO_RB:
+        return 'igemm_halo_rb_kernel<{k},%s>' % ('f16' if prec == 'f16x3' else 'bf16')
     if halo:
         return 'igemm_halo_kernel<{k},%s,%s>' % (_HTAG[prec], cfg)
     base = 'igemm_kernel' if prec == 'f32' else 'igemm_split_kernel'
@@ -340,7 +346,7 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
         flops = 2.0 * n * ho * wo * spec.cin * spec.cout * spec.k * spec.k
     else:
         flops = 2.0 * n * h * w_ * spec.cin * spec.cout * spec.k * spec.k
-    with _Prof(_igemm_name(d.y.C, halo, prec).replace('{k}', str(spec.k)), flops):
+    with _Prof(_igemm_name(d.y.C, halo, prec, xv.C).replace('{k}', str(spec.k)), flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
     return out
 
@@ -377,7 +383,7 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     d.y_amax, keep_y = _out_amax(prec, y_amax, yv._src)
     side = d.x if spec.kind == 'c' else yv          # the conv's output side
     flops = 2.0 * side.N * side.H * side.W * spec.cin * spec.cout * spec.k * spec.k
-    with _Prof(_igemm_name(yv.C, as_fwd, prec).replace('{k}', str(spec.k)), flops):
+    with _Prof(_igemm_name(yv.C, as_fwd, prec, dzv.C).replace('{k}', str(spec.k)), flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
 
 

@@ -1,0 +1,51 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): collects the rocprofv3 evidence bench.py's numbers are
+# judged against and writes compact summaries under gpurun_out/profiles_<tag>/ :
+#   <tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-chn` (DFPN cfg2 only, so per-kernel averages are those of the roofline line)
+#   <tag>_bench_under_rocprof.json the bench line printed in that run
+#   <tag>_pmc_hbm_traffic.txt      FETCH_SIZE / WRITE_SIZE (separate passes) per kernel, DFPN cfg2 step (eager) + correlation micro-bench
+# usage: tools/collect_profiles.sh <tag>
+set -u
+export TMPDIR=/tmp
+tag=${1:-r01}
+out=gpurun_out/profiles_$tag
+mkdir -p $out
+rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-chn > $out/${tag}_bench_under_rocprof.json 2> $out/stats.err || echo "stats run failed"
+cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/${tag}_bench_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace -d $out/pmc_$c -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-chn --no-graph > $out/pmc_$c.json 2> $out/pmc_$c.err || echo "pmc $c failed"
+done
+python3 - "$out" "$tag" <<'PY'
+import csv, glob, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+def load(counter):
+    f = glob.glob(f'{out}/pmc_{counter}/**/*counter_collection.csv', recursive=True)
+    acc = collections.defaultdict(list)
+    if not f:
+        return acc
+    for r in csv.DictReader(open(f[0])):
+        if r['Counter_Name'] == counter:
+            acc[r['Kernel_Name']].append((float(r['Counter_Value']), (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e6))
+    return acc
+fe, wr = load('FETCH_SIZE'), load('WRITE_SIZE')
+rows = []
+for k in fe:
+    n = len(fe[k])
+    f = sum(v for v, _ in fe[k]) / n
+    w = sum(v for v, _ in wr.get(k, [(0, 0)])) / max(1, len(wr.get(k, [1])))
+    ms = sum(t for _, t in fe[k]) / n
+    mb = (2 * f + w) * 1024 / 1e6
+    rows.append((mb * n, k, n, f, w, mb, ms))
+rows.sort(reverse=True)
+with open(f'{out}/{tag}_pmc_hbm_traffic.txt', 'w') as o:
+    o.write('# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-chn --no-graph\n')
+    o.write('# (DFPN cfg2 steps, eager launches, + the 2048-pair correlation micro-benchmark).  Units: KB per dispatch; gfx950 correction\n')
+    o.write('# (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of a wide coalesced stream -> bytes = (2*FETCH + WRITE) * 1024\n')
+    o.write('kernel,launches,avg_FETCH_SIZE_KB,avg_WRITE_SIZE_KB,corrected_MB_per_launch,avg_ms_under_pmc,corrected_GB_per_s\n')
+    for _, k, n, f, w, mb, ms in rows[:40]:
+        name = k.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '').split('(')[0]
+        o.write(f'{name},{n},{f:.1f},{w:.1f},{mb:.1f},{ms:.3f},{mb / ms if ms else 0:.0f}\n')
+print(open(f'{out}/{tag}_pmc_hbm_traffic.txt').read()[:3000])
+PY
+rm -rf $out/stats $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+ls -la $out
