@@ -392,9 +392,15 @@ def _splits(blocks_base, pixels):
     return max(1, min(s, 512))
 
 
-def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_amax=None, x_amax=None):
+def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_amax=None, x_amax=None, sub_blocks=None):
     """(dW, db) of one layer.  dz: (N,Ho,Wo,CoP) gradient wrt the layer's
-    pre-activation output; xin_view: mt_view of the layer's input."""
+    pre-activation output; xin_view: mt_view of the layer's input.
+
+    ``sub_blocks`` = [(a0, cout_i, cin_i, w_i), ...]: ONE launch for several
+    Conv2d layers that read channel prefixes of the same input and whose output
+    gradients sit side by side in ``dz`` (the four growth convs of a dense
+    block): the launch forms the whole (sum cout_i) x (max cin_i) product and
+    every layer takes its sub-block of the slabs.  Returns [(dW_i, db_i), ...]."""
     dzv = view_of(dz)
     if spec.kind == 'c':
         dv, gv, a, b = dzv, xin_view, spec.cout, spec.cin
@@ -440,8 +446,20 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
         kname = f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else 1},{_HTAG[prec]}>'
     else:
         kname = ('wgrad_kernel' if prec == 'f32' else 'wgrad_split_kernel') + f'<{wcfg}{_KTAG[prec]}>'
-    with _Prof(kname, 2.0 * pixels * spec.cin * spec.cout * t):
+    useful = spec.cin * spec.cout if sub_blocks is None else sum(ca * cb for _, ca, cb, _ in sub_blocks)
+    with _Prof(kname, 2.0 * pixels * useful * t):     # (algorithmic FLOP: only the sub-blocks that are kept)
         L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
+    if sub_blocks is not None:
+        assert spec.kind == 'c' and (fused_bias or not need_bias)
+        outs = []
+        for a0, ca, cb, wi in sub_blocks:
+            dwi = torch.empty_like(wi)
+            dbi = torch.empty((ca,), device=wi.device, dtype=torch.float32) if need_bias else None
+            # sub-block rows a0.. of every slab (the slab stride stays that of the whole launch)
+            L.call('mt_wgrad_reduce', C.c_void_p(slabs.data_ptr() + 4 * a0 * ts * bp), d.splits, ap, t, ts, bp,
+                   L.ptr(dwi), ca, cb, cb * t, t, 1, 0, scale, L.ptr(dbi) if fused_bias else None, L.stream_ptr())
+            outs.append((dwi, dbi))
+        return outs
     dw = torch.empty_like(w)
     db = torch.empty((spec.cout,), device=w.device, dtype=torch.float32) if need_bias else None
     # both Conv2d (O,I,k,k) and ConvTranspose2d (I,O,k,k): a = dim 0, b = dim 1

@@ -12,6 +12,8 @@ gradients in place.
 import ctypes as C
 import functools
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -116,6 +118,9 @@ class RRDBNetFn(torch.autograd.Function):
             return E.LayerSpec('c', cin, cout, 3, stride, NONE, ups)
 
         f16 = E.PRECISION == 'f16x3'
+        # one weight-gradient launch per dense block instead of four (halo-tile path only: it
+        # carries the bias sums along); MT355_RDB_BATCHED_WGRAD=0 restores the per-layer launches
+        batched_wgrad = E.USE_HALO and E.PRECISION != 'f32' and os.environ.get('MT355_RDB_BATCHED_WGRAD', '1') != '0'
 
         def wgrad(key, sp, dz, xin, scale=1.0, x_amax=None, dz_amax=None):
             dw, db = E.conv_backward_weight(sp, dz, E.view_of(xin), P[key + '.weight'], scale=scale, x_amax=x_amax,
@@ -167,10 +172,21 @@ class RRDBNetFn(torch.autograd.Function):
                     cin = nf + (i - 1) * gc
                     spi = spec(cin, gc)
                     dzi = dbuf[..., cin: cin + gc]
-                    wgrad(f'{key}conv{i}', spi, dzi, buf[..., :cin], x_amax=buf_amax, dz_amax=dba)
+                    if not batched_wgrad:
+                        wgrad(f'{key}conv{i}', spi, dzi, buf[..., :cin], x_amax=buf_amax, dz_amax=dba)
                     E.conv_backward_data(spi, dzi, P[f'{key}conv{i}.weight'], E.view_of(dbuf[..., :cin]), dsrc=buf,
                                          dact=LRELU if i > 1 else NONE, dact_c0=cin - gc if i > 1 else 0,
                                          accumulate=True, dz_amax=dba, y_amax=dba)
+                if batched_wgrad:
+                    # the four growth convs read channel prefixes of ``buf`` and their (now final) output
+                    # gradients are the adjacent windows dbuf[nf : nf + 4 gc]: one weight-gradient launch
+                    # over the whole 4 gc x (nf + 3 gc) product, each layer takes its sub-block
+                    subs = [((i - 1) * gc, gc, nf + (i - 1) * gc, P[f'{key}conv{i}.weight']) for i in (1, 2, 3, 4)]
+                    res = E.conv_backward_weight(spec(nf + 3 * gc, 4 * gc), dbuf[..., nf: nf + 4 * gc],
+                                                 E.view_of(buf[..., :nf + 3 * gc]), P[f'{key}conv1.weight'],
+                                                 x_amax=buf_amax, dz_amax=dba, sub_blocks=subs)
+                    for i, (dw, db) in zip((1, 2, 3, 4), res):
+                        G[f'{key}conv{i}.weight'], G[f'{key}conv{i}.bias'] = dw, db
                 # grad wrt the block input: dense part + residual path
                 d_in = torch.empty((n, h, w, nf), device=dy.device, dtype=torch.float32)
                 _axpby(dbuf[..., :nf], 1.0, d_rdb, s_rdb, d_in)
