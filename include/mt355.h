@@ -186,6 +186,17 @@ int mt_weight_pack_halo(const float* src, int32_t A, int32_t B, int32_t T,
                         int64_t sa, int64_t sb, int64_t st, void* dst,
                         int32_t AP, int32_t BP, int32_t precision, int32_t flip,
                         const float* w_amax, void* stream);
+/* One K-part of a STACKED weight image: the B (input-channel) axis of the packed
+ * tiles is the concatenation of several sources (e.g. the layers whose output
+ * gradients a dense block's backward gathers in one launch, model_chn.py:618-622);
+ * this call writes channels [b_off, b_off + BP) of BP_total (b_off and every
+ * part but the last a multiple of the K chunk: 32, 16 for BF16X6).  All parts
+ * share AP, the precision and (F16X3) one w_amax >= max|W| over the stack. */
+int mt_weight_pack_halo_part(const float* src, int32_t A, int32_t B, int32_t T,
+                             int64_t sa, int64_t sb, int64_t st, void* dst,
+                             int32_t AP, int32_t BP, int32_t precision,
+                             int32_t flip, const float* w_amax, int32_t BP_total,
+                             int32_t b_off, void* stream);
 /* out[0] = max(out[0], max |x|) over an NHWC4 view / a flat array (atomic max on
  * the device scalar: zero it first; several calls may share one scalar). */
 int mt_absmax(const mt_view* x, float* out, void* stream);

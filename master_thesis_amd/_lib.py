@@ -67,6 +67,7 @@ SIGNATURES = {
     'mt_weight_pack': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, _vp],
     'mt_weight_pack_split': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp, _vp],
     'mt_weight_pack_halo': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp, _vp],
+    'mt_weight_pack_halo_part': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp, i32, i32, _vp],
     'mt_absmax': [_P(View), _vp, _vp],
     'mt_absmax_flat': [_vp, i64, _vp, _vp],
     'mt_weight_pack_halo_elems': [i32, i32, i32, i32],

@@ -651,7 +651,8 @@ namespace {
 // dst[tap][chunk][ntile][plane][BN][LD]: the LDS image of every weight tile of
 // igemm_halo_kernel (pad columns and out-of-range rows/channels are zero)
 __global__ void weight_pack_halo_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
-                                        int BN, int CK, int NS, int nchunk, int ntile, int flip, const float* wamax) {
+                                        int BN, int CK, int NS, int nchunk, int ntile, int flip, const float* wamax,
+                                        int nchunk_total, int ch_off) {
   const float sc = wamax ? pow2_scale(*wamax) : 1.f;    // F16X3: fp16 planes of W * 2^k
   const int LD = CK + 8;
   const long tile_e = (long)NS * BN * LD;
@@ -666,7 +667,7 @@ __global__ void weight_pack_halo_kernel(const float* src, int A, int B, int T, l
     const int a = nt * BN + row, b = ch * CK + col;
     float v = 0.f;
     if (col < CK && a < A && b < B) v = src[a * sa + b * sb + (flip ? T - 1 - t : t) * st];
-    __bf16* tile = dst + ((long)(t * nchunk + ch) * ntile + nt) * tile_e;
+    __bf16* tile = dst + ((long)(t * nchunk_total + ch_off + ch) * ntile + nt) * tile_e;
     if (wamax) {
       v *= sc;
       const _Float16 h = (_Float16)v;
@@ -685,7 +686,8 @@ __global__ void weight_pack_halo_kernel(const float* src, int A, int B, int T, l
 // Fragment-order weights of igemm_halo_rb_kernel: dst[tap][chunk][ntile][wave 4][kstep 2][plane 2][lane 64][8]:
 // lane (li = lane & 31, lh = lane >> 5) holds W[a = ntile*128 + wave*32 + li][b = chunk*32 + kstep*16 + 8*lh + j]
 __global__ void weight_pack_halo_rb_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
-                                           int nchunk, int ntile, int flip, const float* wamax) {
+                                           int nchunk, int ntile, int flip, const float* wamax, int nchunk_total,
+                                           int ch_off) {
   const float sc = wamax ? pow2_scale(*wamax) : 1.f;
   const long total = (long)T * nchunk * ntile * 4 * 2 * 64 * 8;      // elements per plane
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -697,7 +699,7 @@ __global__ void weight_pack_halo_rb_kernel(const float* src, int A, int B, int T
     const int a = nt * 128 + wv * 32 + (lane & 31), b = ch * 32 + ks * 16 + 8 * (lane >> 5) + j;
     float v = 0.f;
     if (a < A && b < B) v = src[a * sa + b * sb + (flip ? T - 1 - t : t) * st];
-    __bf16* o = dst + ((((((long)t * nchunk + ch) * ntile + nt) * 4 + wv) * 2 + ks) * 2) * 512 + lane * 8 + j;
+    __bf16* o = dst + ((((((long)t * nchunk_total + ch_off + ch) * ntile + nt) * 4 + wv) * 2 + ks) * 2) * 512 + lane * 8 + j;
     if (wamax) {
       v *= sc;
       const _Float16 h = (_Float16)v;
@@ -718,27 +720,43 @@ extern "C" int64_t mt_weight_pack_halo_elems(int32_t AP, int32_t BP, int32_t T, 
   return (int64_t)T * ((BP + CK - 1) / CK) * ((AP + BN - 1) / BN) * NS * BN * LD;
 }
 
-extern "C" int mt_weight_pack_halo(const float* src, int32_t A, int32_t B, int32_t T, int64_t sa, int64_t sb,
-                                   int64_t st, void* dst, int32_t AP, int32_t BP, int32_t precision, int32_t flip,
-                                   const float* w_amax, void* stream) {
+static int pack_halo_impl(const float* src, int32_t A, int32_t B, int32_t T, int64_t sa, int64_t sb, int64_t st,
+                          void* dst, int32_t AP, int32_t BP, int32_t precision, int32_t flip, const float* w_amax,
+                          int32_t BP_total, int32_t b_off, void* stream) {
   MT_REQUIRE(src && dst && A <= AP && B <= BP && (BP & 7) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0,
              "mt_weight_pack_halo: bad arguments");
   MT_REQUIRE(precision == MT_PREC_BF16X3 || precision == MT_PREC_BF16X6 || precision == MT_PREC_F16X3,
              "mt_weight_pack_halo: precision");
   MT_REQUIRE((precision == MT_PREC_F16X3) == (w_amax != nullptr), "mt_weight_pack_halo: w_amax goes with F16X3");
   const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = NS == 3 ? 16 : 32;
+  MT_REQUIRE(b_off >= 0 && b_off % CK == 0 && b_off + BP <= BP_total && (b_off + BP == BP_total || BP % CK == 0),
+             "mt_weight_pack_halo_part: a part must cover whole %d-channel K chunks", CK);
   const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);        // the n-tile igemm_halo uses for Co = AP
   const int nchunk = (BP + CK - 1) / CK, ntile = (AP + BN - 1) / BN;
-  if (BN == 128 && NS == 2 && halo_rb_wanted(BP)) {     // fragment order for igemm_halo_rb_kernel (fits the same buffer)
+  const int nchunk_total = (BP_total + CK - 1) / CK, ch_off = b_off / CK;
+  if (BN == 128 && NS == 2 && halo_rb_wanted(BP_total)) {     // fragment order for igemm_halo_rb_kernel (fits the same buffer)
     const long tot = (long)T * nchunk * ntile * 4096;
     hipLaunchKernelGGL(weight_pack_halo_rb_kernel, dim3(mt_grid_1d(tot, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), src, A, B, T, (long)sa, (long)sb, (long)st,
-                       reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, w_amax);
+                       reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, w_amax, nchunk_total, ch_off);
     return mt_check_launch("mt_weight_pack_halo(rb)");
   }
   const long total = (long)T * nchunk * ntile * BN * (CK + 8);
   hipLaunchKernelGGL(weight_pack_halo_kernel, dim3(mt_grid_1d(total, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), src, A, B, T, (long)sa, (long)sb, (long)st,
-                     reinterpret_cast<__bf16*>(dst), BN, CK, NS, nchunk, ntile, flip, w_amax);
+                     reinterpret_cast<__bf16*>(dst), BN, CK, NS, nchunk, ntile, flip, w_amax, nchunk_total, ch_off);
   return mt_check_launch("mt_weight_pack_halo");
+}
+
+extern "C" int mt_weight_pack_halo(const float* src, int32_t A, int32_t B, int32_t T, int64_t sa, int64_t sb,
+                                   int64_t st, void* dst, int32_t AP, int32_t BP, int32_t precision, int32_t flip,
+                                   const float* w_amax, void* stream) {
+  return pack_halo_impl(src, A, B, T, sa, sb, st, dst, AP, BP, precision, flip, w_amax, BP, 0, stream);
+}
+
+extern "C" int mt_weight_pack_halo_part(const float* src, int32_t A, int32_t B, int32_t T, int64_t sa, int64_t sb,
+                                        int64_t st, void* dst, int32_t AP, int32_t BP, int32_t precision,
+                                        int32_t flip, const float* w_amax, int32_t BP_total, int32_t b_off,
+                                        void* stream) {
+  return pack_halo_impl(src, A, B, T, sa, sb, st, dst, AP, BP, precision, flip, w_amax, BP_total, b_off, stream);
 }

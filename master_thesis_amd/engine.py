@@ -254,6 +254,50 @@ def _pack(w, a_dim, kind, prec, flip=False, halo=False):
     return out, wa
 
 
+def stack_amax(weights):
+    """One device scalar >= max|w| over several weights (the scale of a stacked pack)."""
+    key = (tuple((w.data_ptr(), w._version) for w in weights), 'stack_amax', WEIGHT_EPOCH)
+    hit = _pack_cache.get(key)
+    if hit is not None:
+        return hit[0]
+    wa = new_amax(weights[0].device)
+    for w in weights:
+        L.call('mt_absmax_flat', L.ptr(w), w.numel(), L.ptr(wa), L.stream_ptr())
+    _pack_cache[key] = (wa, list(weights))
+    return wa
+
+
+def pack_stacked_bwd(sources, a0, a_cnt, prec, wa=None):
+    """Halo-kernel weight image of the GATHER form of a backward-data through
+    several Conv2d layers at once: the launch's K axis is the concatenation of
+    the output channels of ``sources`` (Conv2d weights (O_l, I_l, k, k), in the
+    order their output gradients sit in the input tensor), its output channels
+    are the input channels [a0, a0 + a_cnt) of every source, taps flipped:
+        dX[:, a0:a0+a_cnt] = sum_l conv_T(dZ_l, W_l[:, a0:a0+a_cnt]).
+    ``wa``: the shared F16X3 scale scalar (stack_amax)."""
+    key = (tuple((w.data_ptr(), w._version) for w in sources), a0, a_cnt, prec, 'stack', WEIGHT_EPOCH)
+    hit = _pack_cache.get(key)
+    if hit is not None:
+        return hit[0], hit[2]
+    assert prec != 'f32'
+    k = sources[0].shape[2]
+    t = k * k
+    ap, bp_total = cpad(a_cnt), sum(cpad(w.shape[0]) for w in sources)
+    if prec == 'f16x3' and wa is None:
+        wa = stack_amax(sources)
+    n = L.load().mt_weight_pack_halo_elems(ap, bp_total, t, _PREC[prec])
+    out = torch.empty((n,), device=sources[0].device, dtype=torch.bfloat16)
+    off = 0
+    for w in sources:
+        o, i = w.shape[0], w.shape[1]
+        assert w.is_contiguous() and a0 + a_cnt <= i and w.shape[2] == k
+        L.call('mt_weight_pack_halo_part', C.c_void_p(w.data_ptr() + 4 * a0 * t), a_cnt, o, t, t, i * t, 1, L.ptr(out),
+               ap, cpad(o), _PREC[prec], 1, L.ptr(wa), bp_total, off, L.stream_ptr())
+        off += cpad(o)
+    _pack_cache[key] = (out, list(sources), wa)
+    return out, wa
+
+
 def _pad_bias(b, n):
     if b is None:
         return None
@@ -352,7 +396,7 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
 
 
 def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, accumulate=False, alpha=1.0,
-                       dz_amax=None, y_amax=None):
+                       dz_amax=None, y_amax=None, packed=None, res=None, beta=0.0):
     """dIn = bwd-data(dZ) written through the view ``yv`` (the layer's input
     geometry), optionally gated by act'(dsrc) (the previous layer's saved
     output)."""
@@ -364,7 +408,11 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     # conv so that it takes the halo-tile kernel
     as_fwd = halo_eligible(spec.kind == 'c', spec.stride, spec.k, dz.shape[3])
     prec = eff_precision(as_fwd)
-    packed, wa = _pack(w, 1 if spec.kind == 'c' else 0, 'bflip' if as_fwd else 'b', prec, flip=as_fwd, halo=as_fwd)
+    if packed is not None:      # a stacked image from pack_stacked_bwd (halo-tile kernels only)
+        assert as_fwd
+        packed, wa = packed
+    else:
+        packed, wa = _pack(w, 1 if spec.kind == 'c' else 0, 'bflip' if as_fwd else 'b', prec, flip=as_fwd, halo=as_fwd)
     d.wt = packed.data_ptr()
     d.wt_layout = 1 if as_fwd else 0
     d.bias = None
@@ -372,7 +420,7 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     d.stride, d.pad, d.ups = spec.stride, spec.pad, 0
     d.transposed = 0 if (spec.kind != 'c' or as_fwd) else 1
     d.act, d.alpha = L.ACT_NONE, alpha
-    d.res, d.beta = null_view(), 0.0
+    d.res, d.beta = (view_of(res), beta) if res is not None else (null_view(), 0.0)
     d.dsrc = view_of(dsrc) if dsrc is not None else null_view()
     d.dact, d.dact_c0 = dact, dact_c0
     d.accumulate = 1 if accumulate else 0

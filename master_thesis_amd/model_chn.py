@@ -107,6 +107,53 @@ class RRDBNetFn(torch.autograd.Function):
         return out, saved
 
     @staticmethod
+    def _rdb_backward_gather(key, P, G, buf, buf_amax, dzb, d_rdb, s_rdb, nf, gc, f16):
+        """Backward of one ResidualDenseBlock5C (model_chn.py:602-623) in GATHER form.
+
+        The layer-by-layer form scatters: the backward-data of conv_i adds into ALL the channels
+        conv_i read (read-modify-write of up to 160 channels per launch, K = 32 only).  Here the
+        gradient of each channel window is produced by ONE launch that gathers from every later
+        layer: the output gradients are kept side by side as dzb = [dz5 | dz4 | dz3 | dz2 | dz1],
+        so window i reads the channel PREFIX [dz5 .. dz(i+1)] against the stacked, tap-flipped
+        weights [W5[:, win_i]; W4[:, win_i]; ...] and writes dz_i (gated by LeakyReLU'(buf[win_i]))
+        right behind it; the last launch gives the block-input gradient with the residual path
+        fused (d_in = dense part + s_rdb * d_rdb).  Same MFMA work, every gradient channel is
+        written once, no accumulate passes.  Returns d_in."""
+        cw = nf + 4 * gc
+        W = [None] + [P[f'{key}conv{i}.weight'] for i in (1, 2, 3, 4, 5)]
+        prec = E.eff_precision(True)
+        wa = E.stack_amax(W[1:]) if prec == 'f16x3' else None
+        dba = E.new_amax(buf.device) if f16 else None
+
+        def spec(cin, cout):
+            return E.LayerSpec('c', cin, cout, 3, 1, NONE, 0)
+
+        # dz5 = (0.2 * s_rdb) * d_rdb
+        _axpby(d_rdb, 0.2 * s_rdb, d_rdb, 0.0, dzb[..., :nf])
+        if f16:
+            E.absmax_into(dzb[..., :nf], dba)
+        dw, db = E.conv_backward_weight(spec(cw, nf), dzb[..., :nf], E.view_of(buf), W[5], x_amax=buf_amax, dz_amax=dba)
+        G[f'{key}conv5.weight'], G[f'{key}conv5.bias'] = dw, db
+        for i in (4, 3, 2, 1):
+            kk = nf + (4 - i) * gc                  # channels of [dz5 .. dz(i+1)]
+            c0 = nf + (i - 1) * gc                  # window of conv_i's output inside buf
+            srcs = [W[l] for l in range(5, i, -1)]
+            E.conv_backward_data(spec(gc, kk), dzb[..., :kk], None, E.view_of(dzb[..., kk: kk + gc]),
+                                 dsrc=buf[..., c0: c0 + gc], dact=LRELU, dz_amax=dba, y_amax=dba,
+                                 packed=E.pack_stacked_bwd(srcs, c0, gc, prec, wa))
+        d_in = torch.empty(d_rdb.shape, device=d_rdb.device, dtype=torch.float32)
+        E.conv_backward_data(spec(nf, cw), dzb, None, E.view_of(d_in), dz_amax=dba,
+                             packed=E.pack_stacked_bwd([W[l] for l in (5, 4, 3, 2, 1)], 0, nf, prec, wa),
+                             res=d_rdb, beta=s_rdb)
+        # the four growth convs: one weight-gradient launch (dz4..dz1 are adjacent, conv_i reads buf[:c0_i])
+        subs = [((4 - i) * gc, gc, nf + (i - 1) * gc, W[i]) for i in (1, 2, 3, 4)]
+        res = E.conv_backward_weight(spec(nf + 3 * gc, 4 * gc), dzb[..., nf: cw], E.view_of(buf[..., :nf + 3 * gc]), W[1],
+                                     x_amax=buf_amax, dz_amax=dba, sub_blocks=subs)
+        for i, (dwi, dbi) in zip((1, 2, 3, 4), res):
+            G[f'{key}conv{i}.weight'], G[f'{key}conv{i}.bias'] = dwi, dbi
+        return d_in
+
+    @staticmethod
     def backward(ctx, dout):
         net, names, S = ctx.net, ctx.names, ctx.saved
         P = dict(zip(names, ctx.saved_tensors))
@@ -121,6 +168,8 @@ class RRDBNetFn(torch.autograd.Function):
         # one weight-gradient launch per dense block instead of four (halo-tile path only: it
         # carries the bias sums along); MT355_RDB_BATCHED_WGRAD=0 restores the per-layer launches
         batched_wgrad = E.USE_HALO and E.PRECISION != 'f32' and os.environ.get('MT355_RDB_BATCHED_WGRAD', '1') != '0'
+        # gather form of the dense-block backward (see _rdb_backward_gather); MT355_RDB_GATHER=0: layer by layer
+        gather = batched_wgrad and os.environ.get('MT355_RDB_GATHER', '1') != '0'
 
         def wgrad(key, sp, dz, xin, scale=1.0, x_amax=None, dz_amax=None):
             dw, db = E.conv_backward_weight(sp, dz, E.view_of(xin), P[key + '.weight'], scale=scale, x_amax=x_amax,
@@ -161,6 +210,10 @@ class RRDBNetFn(torch.autograd.Function):
             for j in (3, 2, 1):
                 key = f'rrdb_trunk.{k}.rdb{j}.'
                 buf, buf_amax = bufs[3 * k + (j - 1)]
+                if gather:
+                    d_rdb = RRDBNetFn._rdb_backward_gather(key, P, G, buf, buf_amax, dbuf, d_rdb, s_rdb, nf, gc, f16)
+                    s_rdb = 1.0
+                    continue
                 # running max|.| of what this block's launches write into dbuf (it bounds every window)
                 dba = E.new_amax(dy.device) if f16 else None
                 # out = 0.2 * conv5(cat) + x  with d(out) = s_rdb * d_rdb
