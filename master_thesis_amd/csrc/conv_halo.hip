@@ -231,9 +231,10 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
 // double-buffered, so a block synchronises ONCE per K chunk (every k*k taps).
 // Fragment slot B[ks] is reloaded for the next tap right after the MFMAs that
 // read it have been issued.
-template <int KS, int FMT>
+template <int KS, int FMT, int WM>
 __global__ __launch_bounds__(256, 2) void igemm_halo_rb_kernel(ConvK p, int tiles_y, int tiles_x) {
-  constexpr int NS = 2, CK = 32, LD = CK + 8, TH = 8, TW = 16, BN = 128, TM = 4;
+  // WM waves along the 128 pixels x WN = 4 / WM waves along the channels: wave = (128 / WM) pixels x 32 channels
+  constexpr int NS = 2, CK = 32, LD = CK + 8, TH = 8, TW = 16, WN = 4 / WM, BN = WN * 32, TM = 4 / WM;
   constexpr int HW_ = TW + KS - 1, HH = TH + KS - 1, HP = HH * HW_;
   constexpr int F4 = CK / 4, NH4 = HP * F4, RH = (NH4 + 255) / 256;
   constexpr int T = KS * KS, KSTEPS = CK / 16;
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_rb_kernel(ConvK p, int tile
   __shared__ __attribute__((aligned(16))) __bf16 sH[2 * HALO_E];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
   int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int tx = bid % tiles_x; bid /= tiles_x;
@@ -288,12 +290,12 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_rb_kernel(ConvK p, int tile
       }
     }
   };
-  // weight fragments: [tap][chunk][ntile][wave][kstep][plane][lane] x 16 B
+  // weight fragments: [tap][chunk][ntile][wn][kstep][plane][lane] x 16 B
   const bf16x8* wfr = reinterpret_cast<const bf16x8*>(p.wt);
   const int nchunk = (p.C + CK - 1) / CK, ntile_w = (p.Co + BN - 1) / BN;
   bf16x8 fb[KSTEPS][NS];
   auto load_B = [&](int ch, int tap, int ks) {
-    const bf16x8* f = wfr + ((((long)tap * nchunk + ch) * ntile_w + blockIdx.y) * 4 + wn) * (KSTEPS * NS * 64) +
+    const bf16x8* f = wfr + ((((long)tap * nchunk + ch) * ntile_w + blockIdx.y) * WN + wn) * (KSTEPS * NS * 64) +
                       ks * NS * 64 + lane;
 #pragma unroll
     for (int s = 0; s < NS; ++s) fb[ks][s] = f[s * 64];
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_rb_kernel(ConvK p, int tile
   const int apx = li < 16 ? li : ((li - HW_) & 15);
   int a_base[TM];
 #pragma unroll
-  for (int a = 0; a < TM; ++a) a_base[a] = ((2 * a + (li >> 4)) * HW_ + apx) * LD + 8 * lh;
+  for (int a = 0; a < TM; ++a) a_base[a] = ((2 * (wm * TM + a) + (li >> 4)) * HW_ + apx) * LD + 8 * lh;
 
   load_halo(0);
 #pragma unroll
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_rb_kernel(ConvK p, int tile
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const int i32 = row & 31;
       const int oy = ty0 + (row >> 4), ox = tx0 + (i32 < 16 ? i32 : ((i32 - HW_) & 15));
       if (oy >= p.Ho || ox >= p.Wo) continue;
@@ -376,27 +378,30 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_rb_kernel(ConvK p, int tile
   if (p.yamax) raise_amax(p.yamax, vmax);
 }
 
-// The register-B kernel is used for 128-wide output tiles with at least two K chunks (with a
-// single chunk -- the 32-channel gradients of the dense blocks -- its exposed first weight
-// fetch costs more than the barriers it saves).  The pack routine applies the same rule.
+// The register-B kernel is used for layers with at least two K chunks (with a single chunk its
+// exposed first weight fetch costs more than the barriers it saves) and more than 32 output
+// channels (a 32-wide tile leaves a wave 6 MFMAs per tap, too few to cover the fragment fetch:
+// measured 129 vs 166 TFLOP/s for the LDS-staged kernel).  The pack routine applies the same rule.
 // MT355_HALO_RB=0 keeps the LDS-staged weight tiles everywhere (A/B switch).
-bool halo_rb_wanted(int cin_p) {
+bool halo_rb_wanted(int cin_p, int cout_p) {
   static const bool on = [] { const char* e = getenv("MT355_HALO_RB"); return !(e && e[0] == '0'); }();
-  return on && cin_p > 32;
+  return on && cin_p > 32 && cout_p > 32;
 }
 
 template <int KS, int NS, int FMT>
 void launch_halo(const ConvK& k, hipStream_t s) {
   const int tiles_y = (k.Ho + 7) / 8, tiles_x = (k.Wo + 15) / 16;
   const unsigned nt = (unsigned)k.N * tiles_y * tiles_x;
-  if (k.Co > 64) {
-    if constexpr (NS == 2) {
-      if (halo_rb_wanted(k.C)) {
-        hipLaunchKernelGGL((igemm_halo_rb_kernel<KS, FMT>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, tiles_y,
-                           tiles_x);
-        return;
-      }
+  if constexpr (NS == 2) {
+    if (halo_rb_wanted(k.C, k.Co)) {
+      if (k.Co > 64)
+        hipLaunchKernelGGL((igemm_halo_rb_kernel<KS, FMT, 1>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, tiles_y, tiles_x);
+      else
+        hipLaunchKernelGGL((igemm_halo_rb_kernel<KS, FMT, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+      return;
     }
+  }
+  if (k.Co > 64) {
     hipLaunchKernelGGL((igemm_halo_kernel<KS, NS, FMT, 2, 2, 2, 2>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k,
                        tiles_y, tiles_x);
   } else if (k.Co > 32) {
@@ -683,23 +688,25 @@ __global__ void weight_pack_halo_kernel(const float* src, int A, int B, int T, l
   }
 }
 
-// Fragment-order weights of igemm_halo_rb_kernel: dst[tap][chunk][ntile][wave 4][kstep 2][plane 2][lane 64][8]:
-// lane (li = lane & 31, lh = lane >> 5) holds W[a = ntile*128 + wave*32 + li][b = chunk*32 + kstep*16 + 8*lh + j]
+// Fragment-order weights of igemm_halo_rb_kernel: dst[tap][chunk][ntile][wn WN][kstep 2][plane 2][lane 64][8],
+// WN = BN / 32 waves along the channels: lane (li = lane & 31, lh = lane >> 5) holds
+// W[a = ntile*BN + wn*32 + li][b = chunk*32 + kstep*16 + 8*lh + j]
 __global__ void weight_pack_halo_rb_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
                                            int nchunk, int ntile, int flip, const float* wamax, int nchunk_total,
-                                           int ch_off) {
+                                           int ch_off, int WN) {
   const float sc = wamax ? pow2_scale(*wamax) : 1.f;
-  const long total = (long)T * nchunk * ntile * 4 * 2 * 64 * 8;      // elements per plane
+  const long total = (long)T * nchunk * ntile * WN * 2 * 64 * 8;      // elements per plane
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), ks = (int)((e >> 9) & 1), wv = (int)((e >> 10) & 3);
-    long r = e >> 12;
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), ks = (int)((e >> 9) & 1);
+    long r = e >> 10;
+    const int wv = (int)(r % WN); r /= WN;
     const int nt = (int)(r % ntile); r /= ntile;
     const int ch = (int)(r % nchunk);
     const int t = (int)(r / nchunk);
-    const int a = nt * 128 + wv * 32 + (lane & 31), b = ch * 32 + ks * 16 + 8 * (lane >> 5) + j;
+    const int a = (nt * WN + wv) * 32 + (lane & 31), b = ch * 32 + ks * 16 + 8 * (lane >> 5) + j;
     float v = 0.f;
     if (a < A && b < B) v = src[a * sa + b * sb + (flip ? T - 1 - t : t) * st];
-    __bf16* o = dst + ((((((long)t * nchunk_total + ch_off + ch) * ntile + nt) * 4 + wv) * 2 + ks) * 2) * 512 + lane * 8 + j;
+    __bf16* o = dst + ((((((long)t * nchunk_total + ch_off + ch) * ntile + nt) * WN + wv) * 2 + ks) * 2) * 512 + lane * 8 + j;
     if (wamax) {
       v *= sc;
       const _Float16 h = (_Float16)v;
@@ -734,11 +741,11 @@ static int pack_halo_impl(const float* src, int32_t A, int32_t B, int32_t T, int
   const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);        // the n-tile igemm_halo uses for Co = AP
   const int nchunk = (BP + CK - 1) / CK, ntile = (AP + BN - 1) / BN;
   const int nchunk_total = (BP_total + CK - 1) / CK, ch_off = b_off / CK;
-  if (BN == 128 && NS == 2 && halo_rb_wanted(BP_total)) {     // fragment order for igemm_halo_rb_kernel (fits the same buffer)
-    const long tot = (long)T * nchunk * ntile * 4096;
+  if (NS == 2 && halo_rb_wanted(BP_total, AP)) {     // fragment order for igemm_halo_rb_kernel (fits the same buffer)
+    const long tot = (long)T * nchunk * ntile * (BN / 32) * 1024;
     hipLaunchKernelGGL(weight_pack_halo_rb_kernel, dim3(mt_grid_1d(tot, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), src, A, B, T, (long)sa, (long)sb, (long)st,
-                       reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, w_amax, nchunk_total, ch_off);
+                       reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, w_amax, nchunk_total, ch_off, BN / 32);
     return mt_check_launch("mt_weight_pack_halo(rb)");
   }
   const long total = (long)T * nchunk * ntile * BN * (CK + 8);

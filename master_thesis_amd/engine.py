@@ -92,8 +92,8 @@ HALO_RB = os.environ.get('MT355_HALO_RB', '1') != '0'     # mirrors halo_rb_want
 def _igemm_name(co, halo, prec, cin_p=0):
     """Name of the kernel mt_conv_run picks (profiling labels only)."""
     cfg = '2,2,2,2' if co > 64 else ('2,2,2,1' if co > 32 else '4,1,1,1')
-    if halo and co > 64 and prec in ('f16x3', 'bf16x3') and cin_p > 32 and HALO_RB:
-        return 'igemm_halo_rb_kernel<{k},%s>' % ('f16' if prec == 'f16x3' else 'bf16')
+    if halo and prec in ('f16x3', 'bf16x3') and cin_p > 32 and co > 32 and HALO_RB:
+        return 'igemm_halo_rb_kernel<{k},%s,%d>' % ('f16' if prec == 'f16x3' else 'bf16', 1 if co > 64 else 2)
     if halo:
         return 'igemm_halo_kernel<{k},%s,%s>' % (_HTAG[prec], cfg)
     base = 'igemm_kernel' if prec == 'f32' else 'igemm_split_kernel'
