@@ -746,11 +746,20 @@ __global__ void bias_grad_partial_kernel(const float* d, long dsn, long dsh, lon
   const int c4 = threadIdx.x % C4, r = threadIdx.x / C4;
   const int HW = Hd * Wd;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (r < rows)
-    for (long pix = (long)blockIdx.x * rows + r; pix < M; pix += (long)gridDim.x * rows) {
-      int n = (int)(pix / HW), rem = (int)(pix - (long)n * HW), y = rem / Wd, x = rem - y * Wd;
-      acc += *reinterpret_cast<const f32x4*>(d + (long)n * dsn + (long)y * dsh + (long)x * dsw + c4 * 4);
+  if (r < rows) {
+    // four independent loads in flight per thread (the block is alone on its CU)
+    const long step = (long)gridDim.x * rows;
+    long pix = (long)blockIdx.x * rows + r;
+    auto at = [&](long q) {
+      int n = (int)(q / HW), rem = (int)(q - (long)n * HW), y = rem / Wd, x = rem - y * Wd;
+      return *reinterpret_cast<const f32x4*>(d + (long)n * dsn + (long)y * dsh + (long)x * dsw + c4 * 4);
+    };
+    for (; pix + 3 * step < M; pix += 4 * step) {
+      const f32x4 v0 = at(pix), v1 = at(pix + step), v2 = at(pix + 2 * step), v3 = at(pix + 3 * step);
+      acc += (v0 + v1) + (v2 + v3);
     }
+    for (; pix < M; pix += step) acc += at(pix);
+  }
   extern __shared__ float sm[];   // [rows][CP]
   if (r < rows) *reinterpret_cast<f32x4*>(&sm[r * CP + c4 * 4]) = acc;
   __syncthreads();
@@ -905,7 +914,7 @@ extern "C" int mt_bias_grad(const mt_view* d, float* db, int32_t C, float* ws, i
   const int rows = 256 / C4 > 0 ? 256 / C4 : 1;
   const int threads = rows * C4;
   int nblk = (M + rows * 8 - 1) / (rows * 8);
-  if (nblk > 128) nblk = 128;
+  if (nblk > 256) nblk = 256;      // ws holds 256 * D.C partial sums
   if (nblk < 1) nblk = 1;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(nblk), dim3(threads), rows * d->C * sizeof(float), s, d->p,
