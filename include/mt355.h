@@ -186,6 +186,38 @@ int mt_weight_pack_halo(const float* src, int32_t A, int32_t B, int32_t T,
                         int64_t sa, int64_t sb, int64_t st, void* dst,
                         int32_t AP, int32_t BP, int32_t precision, int32_t flip,
                         const float* w_amax, void* stream);
+/* ---- batched re-pack: every weight image of a model in two launches ---------
+ * The packs are a pure function of the parameters, and the set of packs a model
+ * needs is the same every step; re-packing after the optimizer step layer by
+ * layer costs ~1300 tiny launches for the CHN step.  The host keeps two tables
+ * in DEVICE memory and replays them once per step. */
+typedef struct {
+  const float* p;      /* segment start */
+  int64_t n;           /* floats */
+  float* out;          /* device scalar, raised to max|p[0..n)| (zero it first); segments may share it */
+} mt_amax_seg;
+int mt_absmax_segments(const mt_amax_seg* segs_dev, int32_t nseg, void* stream);
+
+enum mt_pack_kind { MT_PACK_SPLIT = 0, MT_PACK_HALO = 1 };
+typedef struct {
+  const float* src;
+  void* dst;
+  const float* w_amax;  /* F16X3 scale scalar or NULL */
+  int64_t sa, sb, st;
+  int32_t A, B, T, AP, BP;
+  int32_t precision;    /* mt_precision (not F32) */
+  int32_t flip;
+  int32_t kind;         /* mt_pack_kind: the arguments of mt_weight_pack_split / mt_weight_pack_halo_part */
+  int32_t BP_total, b_off;   /* MT_PACK_HALO: stacked K parts (BP_total == BP, b_off == 0 for a plain pack) */
+  int32_t frag_order;   /* MT_PACK_HALO: mt_weight_pack_halo_frag_order(AP, BP_total, precision) */
+} mt_pack_job;
+/* 1 when mt_weight_pack_halo writes MFMA-fragment order for this shape (the register-B
+ * kernel's layout) rather than LDS tile images; the kernels choose by the same rule. */
+int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, int32_t precision);
+/* jobs_dev: njobs entries in device memory; equivalent to calling the single-pack
+ * entry point of every job.  jobs_host: the same table in host memory (argument checks). */
+int mt_weight_pack_jobs(const mt_pack_job* jobs_dev, const mt_pack_job* jobs_host, int32_t njobs, void* stream);
+
 /* One K-part of a STACKED weight image: the B (input-channel) axis of the packed
  * tiles is the concatenation of several sources (e.g. the layers whose output
  * gradients a dense block's backward gathers in one launch, model_chn.py:618-622);

@@ -43,6 +43,18 @@ class WarpLayout(C.Structure):
                 ('ob', i64), ('oc', i64), ('of', i64), ('wb', i64), ('wf', i64)]
 
 
+class AmaxSeg(C.Structure):
+    _fields_ = [('p', C.c_void_p), ('n', i64), ('out', C.c_void_p)]
+
+
+class PackJob(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('w_amax', C.c_void_p),
+                ('sa', i64), ('sb', i64), ('st', i64),
+                ('A', i32), ('B', i32), ('T', i32), ('AP', i32), ('BP', i32),
+                ('precision', i32), ('flip', i32), ('kind', i32), ('BP_total', i32), ('b_off', i32),
+                ('frag_order', i32)]
+
+
 class PackSrc(C.Structure):
     _fields_ = [('p', C.c_void_p), ('sb', i64), ('sr', i64), ('sc', i64),
                 ('sy', i64), ('sx', i64), ('C', i32), ('c_off', i32),
@@ -69,6 +81,9 @@ SIGNATURES = {
     'mt_weight_pack_halo': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp, _vp],
     'mt_weight_pack_halo_part': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp, i32, i32, _vp],
     'mt_absmax': [_P(View), _vp, _vp],
+    'mt_absmax_segments': [_vp, i32, _vp],
+    'mt_weight_pack_jobs': [_vp, _vp, i32, _vp],
+    'mt_weight_pack_halo_frag_order': [i32, i32, i32],
     'mt_absmax_flat': [_vp, i64, _vp, _vp],
     'mt_weight_pack_halo_elems': [i32, i32, i32, i32],
     'mt_pad_vector': [_vp, i32, _vp, i32, _vp],

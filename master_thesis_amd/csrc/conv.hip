@@ -676,29 +676,7 @@ __global__ __launch_bounds__(256) void wgrad_split_kernel(WgK p) {
 // term, Kp = row length padded to a multiple of 32 with zeros
 __global__ void weight_pack_split_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
                                          int AP, int BP, int Kp, int NS, int flip, const float* wamax) {
-  const long total = (long)AP * Kp;
-  const float sc = wamax ? pow2_scale(*wamax) : 1.f;    // F16X3: fp16 planes of W * 2^k
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(e % Kp);
-    const int a = (int)(e / Kp);
-    float v = 0.f;
-    if (k < T * BP) {
-      const int t = k / BP, b = k - t * BP;
-      if (a < A && b < B) v = src[a * sa + b * sb + (flip ? T - 1 - t : t) * st];
-    }
-    if (wamax) {
-      v *= sc;
-      const _Float16 h = (_Float16)v;
-      dst[e] = __builtin_bit_cast(__bf16, h);
-      dst[total + e] = __builtin_bit_cast(__bf16, (_Float16)(v - (float)h));
-      continue;
-    }
-    for (int s = 0; s < NS; ++s) {
-      const __bf16 h = (__bf16)v;
-      dst[s * total + e] = h;
-      v -= (float)h;
-    }
-  }
+  pack_split_body(src, A, B, T, sa, sb, st, dst, AP, BP, Kp, NS, flip, wamax);
 }
 
 // dst[a][t][b] (+)= sum_s slabs[s][a][t][b]; 256 threads = 64 consecutive

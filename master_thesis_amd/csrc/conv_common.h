@@ -225,3 +225,31 @@ inline int fill_convk(const mt_conv* d, ConvK* k) {
 
 
 }  // namespace
+
+// packed weights for the generic split kernels: dst[plane][a][Kp] (see mt_weight_pack_split)
+__device__ __forceinline__ void pack_split_body(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
+                                         int AP, int BP, int Kp, int NS, int flip, const float* wamax) {
+  const long total = (long)AP * Kp;
+  const float sc = wamax ? pow2_scale(*wamax) : 1.f;    // F16X3: fp16 planes of W * 2^k
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % Kp);
+    const int a = (int)(e / Kp);
+    float v = 0.f;
+    if (k < T * BP) {
+      const int t = k / BP, b = k - t * BP;
+      if (a < A && b < B) v = src[a * sa + b * sb + (flip ? T - 1 - t : t) * st];
+    }
+    if (wamax) {
+      v *= sc;
+      const _Float16 h = (_Float16)v;
+      dst[e] = __builtin_bit_cast(__bf16, h);
+      dst[total + e] = __builtin_bit_cast(__bf16, (_Float16)(v - (float)h));
+      continue;
+    }
+    for (int s = 0; s < NS; ++s) {
+      const __bf16 h = (__bf16)v;
+      dst[s * total + e] = h;
+      v -= (float)h;
+    }
+  }
+}

