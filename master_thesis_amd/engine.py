@@ -319,7 +319,7 @@ def _pack(w, a_dim, kind, prec, flip=False, halo=False):
         wa = _weight_amax(w) if prec == 'f16x3' else None
         if halo:
             n = L.load().mt_weight_pack_halo_elems(cpad(a), cpad(b), t, _PREC[prec])
-            out = torch.empty((n,), device=w.device, dtype=torch.bfloat16)
+            out = torch.zeros((n,), device=w.device, dtype=torch.bfloat16)   # (the image may be shorter than the bound)
         else:
             kp = (t * cpad(b) + 31) // 32 * 32
             out = torch.empty((3 if prec == 'bf16x6' else 2, cpad(a), kp), device=w.device, dtype=torch.bfloat16)
@@ -349,7 +349,7 @@ def pack_stacked_bwd(sources, a0, a_cnt, prec, wa=None):
         if prec == 'f16x3' and wa is None:
             wa = stack_amax(sources)
         n = L.load().mt_weight_pack_halo_elems(ap, bp_total, t, _PREC[prec])
-        out = torch.empty((n,), device=sources[0].device, dtype=torch.bfloat16)
+        out = torch.zeros((n,), device=sources[0].device, dtype=torch.bfloat16)
         jobs, off = [], 0
         for w in sources:
             o, i = w.shape[0], w.shape[1]

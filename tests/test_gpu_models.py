@@ -303,6 +303,41 @@ def test_graph_without_optimizer_sees_weight_updates(mt, dfpn_sd):
     np.testing.assert_allclose(l1, l1_eager, rtol=1e-4)
 
 
+def test_pack_registry_follows_the_parameters(mt, dfpn_sd):
+    """After replays of a graph that contains the optimizer, every registered weight
+    pack (refreshed by the two batched launches inside the graph) is bit-identical
+    to a fresh single-launch pack of the CURRENT parameters, and every layer scale
+    scalar equals max|w|."""
+    import ctypes
+    from master_thesis_amd import engine as E, _lib as L
+    from master_thesis_amd.graph import GraphedTrainStep
+    batch = to_dev(S.synthetic_batch(1, 2, 64, 64, seed=13, flows_use=[True]))
+    model = mt.DFPN(mt.VGGFeatures(device=DEV), **KW)
+    model.load_state_dict(dfpn_sd)
+    model = model.to(DEV)
+    opt = model.configure_optimizers()['optimizer']
+    opt.param_groups[0]['lr'] = 1e-3
+    g = GraphedTrainStep(model, opt, batch, include_optimizer=True, warmup=1)
+    p0 = opt.flat_p.clone()
+    for _ in range(3):
+        g.step()
+    torch.cuda.synchronize()
+    assert float((opt.flat_p - p0).abs().max()) > 0           # the parameters did move
+    assert len(E._packs) > 20
+    for key, ent in E._packs.items():
+        fresh = torch.zeros_like(ent.out)
+        for j in ent.jobs:
+            j2 = L.PackJob()
+            ctypes.memmove(ctypes.byref(j2), ctypes.byref(j), ctypes.sizeof(j))
+            j2.dst = fresh.data_ptr()
+            E._run_job(j2)
+        torch.cuda.synchronize()
+        assert torch.equal(fresh.view(torch.int16), ent.out.view(torch.int16)), key
+    for key, ent in E._wamax.items():
+        want = max(float(w.abs().max()) for w in ent.weights)
+        assert float(ent.out) == want, (key, float(ent.out), want)
+
+
 def test_device_side_adam_replays(mt):
     """The capturable Adam (step counter and lr on the device) replayed from a
     graph equals torch.optim.Adam step for step."""
