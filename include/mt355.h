@@ -288,6 +288,11 @@ int mt_dact(const mt_view* x, const mt_view* s, int32_t act, const mt_view* y,
 int mt_corr_masked(const mt_view* ft, const mt_view* fr, const float* vt,
                    const float* vr, int32_t B, int32_t R, float* out, float* ws,
                    void* stream);
+/* CorrelationVGG.softmax_3d (model_dfpn.py:567-583) on the volume mt_corr_masked
+ * writes: for every (clip b, target position pt) a softmax over the R * P values
+ * x[(b*R + r)][pt][0..P) of all R reference frames jointly (P % 4 == 0).  One wave
+ * per row, maximum and sum by wave shuffles; out may alias x. */
+int mt_softmax3d(const float* x, int32_t B, int32_t R, int32_t P, float* out, void* stream);
 /* out[row][c] = x[row][c]*v[row] / (||x[row]*v[row]||_2 + 1e-9), rows = pixels */
 int mt_rownorm(const mt_view* x, const float* v, float* out, void* stream);
 

@@ -96,6 +96,7 @@ SIGNATURES = {
     'mt_dact': [_P(View), _P(View), i32, _P(View), _vp],
     'mt_corr_masked': [_P(View), _P(View), _vp, _vp, i32, i32, _vp, _vp, _vp],
     'mt_rownorm': [_P(View), _vp, _vp, _vp],
+    'mt_softmax3d': [_vp, i32, i32, i32, _vp, _vp],
     'mt_warp_fwd': [_vp, _vp, _vp, _P(WarpLayout), i32, _vp, _vp, _vp, _vp],
     'mt_warp_bwd_grid': [_vp, _vp, _vp, _P(WarpLayout), i32, _vp, _vp],
     'mt_resize_fwd': [_vp, i64, i64, i64, i32, i32, i32, _vp, i64, i64, i64, i32, i32, i32, i32, _vp],

@@ -495,6 +495,42 @@ __global__ void absmax_flat_kernel(const float* x, long n, float* out) {
   block_amax(m, out);
 }
 
+// 3D softmax of the correlation volume (model_dfpn.py:567-583): row = (clip b, target position pt),
+// its R * P values live in R slabs, P contiguous floats each.  One wave per row: every lane keeps
+// its values in registers between the two reductions when the row is short enough.
+__global__ __launch_bounds__(256) void softmax3d_kernel(const float* x, int R, int P, float* out, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long b = row / P;
+  const int pt = (int)(row - b * P);
+  const long PP = (long)P * P;
+  const float* src = x + (b * R) * PP + (long)pt * P;
+  float* dst = out + (b * R) * PP + (long)pt * P;
+  float m = -INFINITY;
+  for (int r = 0; r < R; ++r)
+    for (int c = lane * 4; c < P; c += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * PP + c);
+      m = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), m);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float sum = 0.f;
+  for (int r = 0; r < R; ++r)
+    for (int c = lane * 4; c < P; c += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + r * PP + c);
+      sum += (expf(v[0] - m) + expf(v[1] - m)) + (expf(v[2] - m) + expf(v[3] - m));
+    }
+  sum = mt_wave_sum(sum);
+  const float inv = 1.f / sum;
+  for (int r = 0; r < R; ++r)
+    for (int c = lane * 4; c < P; c += 256) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(src + r * PP + c);
+      v[0] = expf(v[0] - m) * inv; v[1] = expf(v[1] - m) * inv; v[2] = expf(v[2] - m) * inv; v[3] = expf(v[3] - m) * inv;
+      *reinterpret_cast<f32x4*>(dst + r * PP + c) = v;
+    }
+}
+
 // row-wise masked L2 normalisation of NHWC4 features (correlation prologue):
 // out[p][c] = x[p][c]*v[p] / (||x[p]*v[p]||_2 + 1e-9); one wave per pixel row
 __global__ void rownorm_kernel(const float* x, long xn, long xh, long xw, int H, int W, int C, const float* v,
@@ -526,6 +562,13 @@ bool same_geom(const mt_view* a, const mt_view* b) { return a->N == b->N && a->H
 }  // namespace
 
 #define S_(x) static_cast<hipStream_t>(x)
+
+extern "C" int mt_softmax3d(const float* x, int32_t B, int32_t R, int32_t P, float* out, void* stream) {
+  MT_REQUIRE(x && out && B > 0 && R > 0 && P > 0 && (P & 3) == 0, "mt_softmax3d: bad arguments");
+  const long rows = (long)B * P;
+  hipLaunchKernelGGL(softmax3d_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, S_(stream), x, R, P, out, rows);
+  return mt_check_launch("mt_softmax3d");
+}
 
 extern "C" int mt_rownorm(const mt_view* x, const float* v, float* out, void* stream) {
   MT_REQUIRE(mt_view_flat(x) && out, "mt_rownorm: bad arguments");

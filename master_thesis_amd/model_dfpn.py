@@ -234,11 +234,11 @@ class CorrelationVGG(nn.Module):
 
     @staticmethod
     def softmax_3d(x):
-        """model_dfpn.py:567-583 (off by default; plain tensor ops)."""
-        b, t, h, w, _, _ = x.size()
-        x = x.permute(0, 2, 3, 4, 5, 1).reshape(b, h, w, -1)
-        x = torch.softmax(x, dim=3)
-        return x.reshape(b, h, w, h, w, t).permute(0, 5, 1, 2, 3, 4)
+        """model_dfpn.py:567-583 (off by default): per target position a softmax over
+        (reference frame, reference position) jointly -- one wave per row in HIP, the
+        maximum and the sum by wave shuffles, no permuted copies.  No gradient (the
+        volume comes from no-grad features)."""
+        return ops.softmax_3d(x)
 
 
 class SeparableConv4d(nn.Module):

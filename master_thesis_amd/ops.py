@@ -192,6 +192,16 @@ def correlation(ft4, fr4, v_t, v_r, b, r):
     return out
 
 
+def softmax_3d(x):
+    """CorrelationVGG.softmax_3d (model_dfpn.py:567-583).  x (B,R,h,w,h,w) contiguous."""
+    _chk(x)
+    x = x.contiguous()
+    b, r, h, w = x.shape[:4]
+    out = torch.empty_like(x)
+    L.call('mt_softmax3d', L.ptr(x), b, r, h * w, L.ptr(out), L.stream_ptr())
+    return out
+
+
 # ---------------------------------------------------------------- losses ---
 class L1SumFn(torch.autograd.Function):
     """sum_i w[b] |a_i m_i - b_i m_i| and (optionally) sum of w*m, as a

@@ -187,6 +187,15 @@ def correlation_masked_4d(t_feats, v_t, r_feats, v_r):
     return torch.matmul(tgt, ref).reshape(b, r, h, w, h, w)
 
 
+def softmax_3d(x):
+    """CorrelationVGG.softmax_3d, model_dfpn.py:567-583: for every target position
+    a softmax over (reference frame, reference position) jointly.  x (B,R,H,W,H,W)."""
+    b, t, h, w = x.shape[:4]
+    y = x.permute(0, 2, 3, 4, 5, 1).reshape(b, h, w, -1)
+    y = torch.softmax(y, dim=3)
+    return y.reshape(b, h, w, h, w, t).permute(0, 5, 1, 2, 3, 4)
+
+
 def _conv(sd, key, x, stride=1, padding=1):
     return F.conv2d(x, sd[key + '.weight'], sd[key + '.bias'], stride=stride,
                     padding=padding)

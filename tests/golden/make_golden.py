@@ -78,6 +78,9 @@ def g1_corr():
         vr = (S.uniform(f'g1.vr.{tag}', (b, 1, r, 16, 16)) > 0.3).float()
         res[f'{tag}.masked'] = M.correlation_masked_4d(ft, vt, fr, vr)
         res[f'{tag}.unmasked'] = M.correlation_masked_4d(ft, None, fr, None)
+        # the optional 3D softmax over (reference frame, reference position), model_dfpn.py:567-583;
+        # scaled so that the distribution is far from uniform
+        res[f'{tag}.softmax'] = M.softmax_3d(res[f'{tag}.masked'] * 20.0)
     save('g1_corr', **res)
 
 

@@ -170,6 +170,10 @@ def test_correlation(mt, golden):
         vr = (S.uniform(f'g1.vr.{tag}', (b, 1, r, 16, 16)) > 0.3).float().to(dev())
         assert_close(M.correlation_masked_4d(ft, vt, fr, vr), torch.from_numpy(g[f'{tag}.masked']), what=tag)
         assert_close(M.correlation_masked_4d(ft, None, fr, None), torch.from_numpy(g[f'{tag}.unmasked']), what=tag)
+        sm = M.softmax_3d(M.correlation_masked_4d(ft, vt, fr, vr) * 20.0)
+        assert_close(sm, torch.from_numpy(g[f'{tag}.softmax']), tol=1e-4, what=tag + '.softmax')
+        rows = sm.permute(0, 2, 3, 1, 4, 5).reshape(b * 256, -1).sum(dim=1)     # every (clip, target position) sums to 1
+        assert float((rows - 1).abs().max()) < 1e-5
 
 
 def test_correlation_properties_at_scale(mt):

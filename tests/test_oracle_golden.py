@@ -34,6 +34,7 @@ def test_g1_correlation(golden):
         vr = (S.uniform(f'g1.vr.{tag}', (b, 1, r, 16, 16)) > 0.3).float()
         close(O.correlation_masked_4d(ft, vt, fr, vr), g[f'{tag}.masked'])
         close(O.correlation_masked_4d(ft, None, fr, None), g[f'{tag}.unmasked'])
+        close(O.softmax_3d(O.correlation_masked_4d(ft, vt, fr, vr) * 20.0), g[f'{tag}.softmax'])
 
 
 def test_g2_warp(golden):
