@@ -459,7 +459,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int off, int ld) {
 
 template <int KS, int KHB, int NS, int FMT, int OCC>
 __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split,
-                                                            int ntiles, int with_bias) {
+                                                            int ntiles, int with_bias, int kh_base) {
   constexpr int TR = 4, TW = 16, PX = TR * TW;           // pixel tile: 4 rows x 16
   constexpr int CH = 64, LD = CH + 8;                    // channel tile and LDS row (bf16)
   constexpr int GH = TR + KHB - 1, GW = TW + KS - 1, GP = GH * GW;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
   int bid = blockIdx.x;
   const int bt = bid % p.btiles; bid /= p.btiles;
   const int at = bid % p.atiles; bid /= p.atiles;
-  const int kh0 = bid * KHB;
+  const int kh0 = kh_base + bid * KHB;     // first kernel row of this block
   const int a0 = at * CH, b0 = bt * CH;
   const int split = blockIdx.y;
   const int t_beg = split * tiles_per_split, t_end = min(ntiles, t_beg + tiles_per_split);
@@ -615,6 +615,14 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
 
 }  // namespace
 
+namespace {
+// MT355_WGRAD5_ROWS=1 restores one kernel row per block for the 5x5 weight gradient (A/B switch)
+bool wgrad5_rows32() {
+  static const bool on = [] { const char* e = getenv("MT355_WGRAD5_ROWS"); return !(e && e[0] == '1'); }();
+  return on;
+}
+}  // namespace
+
 // Called by mt_wgrad_run: returns 1 if the launch was taken by the halo kernel.
 // `splits` blocks along y each own a contiguous range of pixel tiles.
 int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
@@ -635,18 +643,23 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   const int ntiles = d->d.N * tiles_y * tiles_x;
   const int tps = (ntiles + d->splits - 1) / d->splits;
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define MT_WGH(KS, KHB, NS, FMT, OCC, GRID) \
-  hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, NS, FMT, OCC>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias)
+#define MT_WGH(KS, KHB, NS, FMT, OCC, GRID, KH_BASE) \
+  hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, NS, FMT, OCC>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
   if (d->KH == 3) {   // all nine taps per block, one block per CU (the 9 accumulator tiles need the registers)
     dim3 grid(k.atiles * k.btiles, d->splits);
-    if (prec == MT_PREC_BF16X6) MT_WGH(3, 3, 3, 0, 1, grid);
-    else if (prec == MT_PREC_BF16X3) MT_WGH(3, 3, 2, 0, 1, grid);
-    else MT_WGH(3, 3, 2, 1, 1, grid);
-  } else {            // one kernel row (5 taps) per block
+    if (prec == MT_PREC_BF16X6) MT_WGH(3, 3, 3, 0, 1, grid, 0);
+    else if (prec == MT_PREC_BF16X3) MT_WGH(3, 3, 2, 0, 1, grid, 0);
+    else MT_WGH(3, 3, 2, 1, 1, grid, 0);
+  } else if (prec == MT_PREC_BF16X6 || !wgrad5_rows32()) {   // one kernel row (5 taps) per block
     dim3 grid(k.atiles * k.btiles * 5, d->splits);
-    if (prec == MT_PREC_BF16X6) MT_WGH(5, 1, 3, 0, 2, grid);
-    else if (prec == MT_PREC_BF16X3) MT_WGH(5, 1, 2, 0, 2, grid);
-    else MT_WGH(5, 1, 2, 1, 2, grid);
+    if (prec == MT_PREC_BF16X6) MT_WGH(5, 1, 3, 0, 2, grid, 0);
+    else if (prec == MT_PREC_BF16X3) MT_WGH(5, 1, 2, 0, 2, grid, 0);
+    else MT_WGH(5, 1, 2, 1, 2, grid, 0);
+  } else {            // kernel rows {0,1,2} and {3,4}: 15 / 10 taps per block, one block per CU; each
+                      // pixel tile is staged twice instead of five times
+    dim3 grid(k.atiles * k.btiles, d->splits);
+    if (prec == MT_PREC_BF16X3) { MT_WGH(5, 3, 2, 0, 1, grid, 0); MT_WGH(5, 2, 2, 0, 1, grid, 3); }
+    else { MT_WGH(5, 3, 2, 1, 1, grid, 0); MT_WGH(5, 2, 2, 1, 1, grid, 3); }
   }
 #undef MT_WGH
   return 1;

@@ -597,7 +597,10 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     halo = USE_HALO and PRECISION != 'f32' and spec.stride == 1 and spec.k in (3, 5)
     prec = eff_precision(halo)
     if halo:   # wgrad_halo_kernel: 64 x 64 channel tiles, all taps (3x3) or one kernel row (5x5) per block
-        blocks = ((ap + 63) // 64) * ((bp + 63) // 64) * (1 if spec.k == 3 else 5)
+        # 3x3: all taps in one block; 5x5: kernel rows {0,1,2} | {3,4} in two launches (bf16x6 and
+        # MT355_WGRAD5_ROWS=1: five one-row blocks) -- mirrors mt_wgrad_halo_try_launch
+        rows5 = prec == 'bf16x6' or os.environ.get('MT355_WGRAD5_ROWS', '0') == '1'
+        blocks = ((ap + 63) // 64) * ((bp + 63) // 64) * (1 if spec.k == 3 else (5 if rows5 else 2))
         ntiles = dv.N * ((dv.H + 3) // 4) * ((dv.W + 15) // 16)
         d.splits = max(1, min((512 + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 256))
     else:
@@ -613,7 +616,7 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     d.d_amax, keep1 = _amax_ptr(prec, da, dv)
     d.g_amax, keep2 = _amax_ptr(prec, ga, gv)
     if halo:
-        kname = f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else 1},{_HTAG[prec]}>'
+        kname = f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else (1 if rows5 else "3+2")},{_HTAG[prec]}>'
     else:
         kname = ('wgrad_kernel' if prec == 'f32' else 'wgrad_split_kernel') + f'<{wcfg}{_KTAG[prec]}>'
     useful = spec.cin * spec.cout if sub_blocks is None else sum(ca * cb for _, ca, cb, _ in sub_blocks)
