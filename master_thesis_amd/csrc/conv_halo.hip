@@ -457,12 +457,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int off, int ld) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int KS, int KHB, int NS, int FMT, int OCC>
+// ST = 2: the gathered tensor is sampled with stride 2 (a stride-2 Conv2d, or a stride-2
+// ConvTranspose2d with the roles of input and output gradient swapped): the patch is
+// (TR-1)*2+KHB x (TW-1)*2+KS pixels and the k rows of a G fragment are every second pixel.
+template <int KS, int KHB, int NS, int FMT, int OCC, int ST = 1>
 __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split,
                                                             int ntiles, int with_bias, int kh_base) {
   constexpr int TR = 4, TW = 16, PX = TR * TW;           // pixel tile: 4 rows x 16
   constexpr int CH = 64, LD = CH + 8;                    // channel tile and LDS row (bf16)
-  constexpr int GH = TR + KHB - 1, GW = TW + KS - 1, GP = GH * GW;
+  constexpr int GH = (TR - 1) * ST + KHB, GW = (TW - 1) * ST + KS, GP = GH * GW;
   constexpr int ND4 = PX * (CH / 4), RD = ND4 / 256;     // float4 loads per thread (D)
   constexpr int NG4 = GP * (CH / 4), RG = (NG4 + 255) / 256;
   constexpr int NT = KHB * KS;
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
     }
 #pragma unroll
     for (int i = 0; i < RG; ++i) {
-      const int ly = ty0 + g_y[i] + kh0 - p.pad, lx = tx0 + g_x[i] - p.pad;
+      const int ly = ty0 * ST + g_y[i] + kh0 - p.pad, lx = tx0 * ST + g_x[i] - p.pad;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (tid + 256 * i < NG4 && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL && b0 + g_c[i] < p.Cg)
         v = *reinterpret_cast<const f32x4*>(gp + (long)(ly >> p.ups) * p.gsh + (long)(lx >> p.ups) * p.gsw + b0 + g_c[i]);
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
   // 16*(g&1).., k rows 8*(g>>1) + q (+4); lane 4q+p supplies row q, columns 4p..
   const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, g1 = (lane >> 4) & 1, lh = lane >> 5;
   const int a_off = (8 * lh + q) * LD + wm * 32 + 16 * g1 + 4 * pp;
-  const int b_off = (8 * lh + q) * LD + wn * 32 + 16 * g1 + 4 * pp;
+  const int b_off = (8 * lh + q) * ST * LD + wn * 32 + 16 * g1 + 4 * pp;
 
   if (t_beg < t_end) load_tile(t_beg);
   for (int t = t_beg; t < t_end; ++t) {
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
         for (int kw = 0; kw < KS; ++kw) {
           bf16x8 fb[NS];
 #pragma unroll
-          for (int s = 0; s < NS; ++s) fb[s] = tr_frag(sG[s], b_off + ((ks + kh) * GW + kw) * LD, LD);
+          for (int s = 0; s < NS; ++s) fb[s] = tr_frag(sG[s], b_off + ((ks * ST + kh) * GW + kw) * LD, ST * LD);
           mfma_splitf<NS, FMT>(fa, fb, acc[kh * KS + kw]);
         }
     }
@@ -617,6 +620,11 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
 
 namespace {
 // MT355_WGRAD5_ROWS=1 restores one kernel row per block for the 5x5 weight gradient (A/B switch)
+// MT355_WGRAD_S2_HALO=0: stride-2 weight gradients stay on the generic kernel (A/B switch)
+bool wgrad_s2_halo() {
+  static const bool on = [] { const char* e = getenv("MT355_WGRAD_S2_HALO"); return !(e && e[0] == '0'); }();
+  return on;
+}
 bool wgrad5_rows32() {
   static const bool on = [] { const char* e = getenv("MT355_WGRAD5_ROWS"); return !(e && e[0] == '1'); }();
   return on;
@@ -628,13 +636,14 @@ bool wgrad5_rows32() {
 int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   const int prec = d->precision;
   if (prec != MT_PREC_BF16X3 && prec != MT_PREC_BF16X6 && prec != MT_PREC_F16X3) return 0;
-  if (d->stride != 1 || d->KH != d->KW || (d->KH != 3 && d->KH != 5) || d->pad != d->KH / 2) return 0;
+  if ((d->stride != 1 && d->stride != 2) || d->KH != d->KW || (d->KH != 3 && d->KH != 5) || d->pad != d->KH / 2) return 0;
+  if (d->stride == 2 && (d->ups != 0 || prec == MT_PREC_BF16X6 || !wgrad_s2_halo())) return 0;
   if (prec == MT_PREC_F16X3 && (!d->d_amax || !d->g_amax)) return 0;
   WgK k;
   k.d = d->d.p; k.dsn = d->d.sn; k.dsh = d->d.sh; k.dsw = d->d.sw; k.Hd = d->d.H; k.Wd = d->d.W; k.Cd = d->d.C;
   k.g = d->g.p; k.gsn = d->g.sn; k.gsh = d->g.sh; k.gsw = d->g.sw; k.Hg = d->g.H; k.Wg = d->g.W; k.Cg = d->g.C;
   k.dni = d->d.n_in; k.dsg = d->d.sg; k.gni = d->g.n_in; k.gsg = d->g.sg;
-  k.KH = d->KH; k.KW = d->KW; k.stride = 1; k.pad = d->pad; k.ups = d->ups;
+  k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.ups = d->ups;
   k.M = d->d.N * d->d.H * d->d.W; k.per_split = 0;
   k.atiles = (k.Cd + 63) / 64; k.btiles = (k.Cg + 63) / 64;
   k.slabs = d->slabs;
@@ -645,7 +654,15 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
 #define MT_WGH(KS, KHB, NS, FMT, OCC, GRID, KH_BASE) \
   hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, NS, FMT, OCC>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
-  if (d->KH == 3) {   // all nine taps per block, one block per CU (the 9 accumulator tiles need the registers)
+#define MT_WGH2(KS, KHB, FMT, GRID, KH_BASE) \
+  hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
+  if (d->stride == 2) {      // stride-2 gather: all 9 taps, or kernel rows {0,1,2} | {3,4}
+    dim3 grid(k.atiles * k.btiles, d->splits);
+    const bool f16 = prec == MT_PREC_F16X3;
+    if (d->KH == 3) { if (f16) MT_WGH2(3, 3, 1, grid, 0); else MT_WGH2(3, 3, 0, grid, 0); }
+    else if (f16) { MT_WGH2(5, 3, 1, grid, 0); MT_WGH2(5, 2, 1, grid, 3); }
+    else { MT_WGH2(5, 3, 0, grid, 0); MT_WGH2(5, 2, 0, grid, 3); }
+  } else if (d->KH == 3) {   // all nine taps per block, one block per CU (the 9 accumulator tiles need the registers)
     dim3 grid(k.atiles * k.btiles, d->splits);
     if (prec == MT_PREC_BF16X6) MT_WGH(3, 3, 3, 0, 1, grid, 0);
     else if (prec == MT_PREC_BF16X3) MT_WGH(3, 3, 2, 0, 1, grid, 0);
@@ -662,6 +679,7 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
     else { MT_WGH(5, 3, 2, 1, 1, grid, 0); MT_WGH(5, 2, 2, 1, 1, grid, 3); }
   }
 #undef MT_WGH
+#undef MT_WGH2
   return 1;
 }
 

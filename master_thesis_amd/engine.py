@@ -595,6 +595,9 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     d.stride, d.pad = spec.stride, spec.pad
     d.ups = spec.ups if spec.kind == 'c' else 0
     halo = USE_HALO and PRECISION != 'f32' and spec.stride == 1 and spec.k in (3, 5)
+    if (USE_HALO and spec.stride == 2 and spec.k in (3, 5) and d.ups == 0 and eff_precision(True) in ('f16x3', 'bf16x3')
+            and os.environ.get('MT355_WGRAD_S2_HALO', '1') != '0'):
+        halo = True        # stride-2 gathers (strided convs, transposed convs) on the halo-tile kernel too
     prec = eff_precision(halo)
     if halo:   # wgrad_halo_kernel: 64 x 64 channel tiles, all taps (3x3) or one kernel row (5x5) per block
         # 3x3: all taps in one block; 5x5: kernel rows {0,1,2} | {3,4} in two launches (bf16x6 and
