@@ -604,7 +604,10 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
         # MT355_WGRAD5_ROWS=1: five one-row blocks) -- mirrors mt_wgrad_halo_try_launch
         rows5 = prec == 'bf16x6' or os.environ.get('MT355_WGRAD5_ROWS', '0') == '1'
         blocks = ((ap + 63) // 64) * ((bp + 63) // 64) * (1 if spec.k == 3 else (5 if rows5 else 2))
-        ntiles = dv.N * ((dv.H + 3) // 4) * ((dv.W + 15) // 16)
+        # pixel tiles of 8 x 16 for the 3x3 stride-1 gradient, 4 x 16 otherwise (as mt_wgrad_halo_try_launch)
+        trows = 8 if (spec.k == 3 and spec.stride == 1 and prec != 'bf16x6'
+                      and os.environ.get('MT355_WGRAD3_TALL', '1') != '0') else 4
+        ntiles = dv.N * ((dv.H + trows - 1) // trows) * ((dv.W + 15) // 16)
         d.splits = max(1, min((512 + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 256))
     else:
         d.splits = _splits(tiles * t, pixels)
