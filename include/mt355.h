@@ -267,9 +267,10 @@ int mt_maxpool2x2(const mt_view* x, const mt_view* y, void* stream);
 /* dX[n,y,x,c] = sum of the 2^ups x 2^ups block of dXup (backward of the
  * nearest up-sampling folded into mt_conv.ups) */
 int mt_sumpool(const mt_view* dxup, const mt_view* dx, int32_t ups, void* stream);
-/* elementwise on NHWC4 views with equal geometry: y = a*x (+ b*z) */
+/* elementwise on NHWC4 views with equal geometry: y = a*x (+ b*z); y_amax: optional
+ * device scalar raised to max|y| (as mt_conv.y_amax), or NULL */
 int mt_axpby(const mt_view* x, float a, const mt_view* z, float b,
-             const mt_view* y, void* stream);
+             const mt_view* y, float* y_amax, void* stream);
 /* y = x * act'(s)  (in place allowed) */
 int mt_dact(const mt_view* x, const mt_view* s, int32_t act, const mt_view* y,
             void* stream);

@@ -92,7 +92,7 @@ SIGNATURES = {
     'mt_pack_pairs': [_P(PackSrc), i32, i32, i32, _P(View), _vp],
     'mt_maxpool2x2': [_P(View), _P(View), _vp],
     'mt_sumpool': [_P(View), _P(View), i32, _vp],
-    'mt_axpby': [_P(View), f32, _P(View), f32, _P(View), _vp],
+    'mt_axpby': [_P(View), f32, _P(View), f32, _P(View), _vp, _vp],
     'mt_dact': [_P(View), _P(View), i32, _P(View), _vp],
     'mt_corr_masked': [_P(View), _P(View), _vp, _vp, i32, i32, _vp, _vp, _vp],
     'mt_rownorm': [_P(View), _vp, _vp, _vp],

@@ -99,9 +99,19 @@ __global__ void sumpool_kernel(const float* x, long xn, long xh, long xw, float*
 }
 
 struct V3 { const float* p; long sn, sh, sw; };
+// wave maximum raised into a device scalar (values >= 0 order like their bit patterns; the plain
+// read filters out almost every wave once the scalar is near its final value)
+__device__ __forceinline__ void wave_raise_amax(float v, float* out) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0 && v > __builtin_nontemporal_load(out))
+    atomicMax(reinterpret_cast<int*>(out), __float_as_int(v));
+}
+
 __global__ void axpby_kernel(V3 x, float a, V3 z, float b, float* y, long yn, long yh, long yw, int N, int H, int W,
-                             int C4) {
+                             int C4, float* yamax) {
   const long total = (long)N * H * W * C4;
+  float m = 0.f;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     int c = (int)(e % C4) * 4;
     long r = e / C4;
@@ -112,7 +122,9 @@ __global__ void axpby_kernel(V3 x, float a, V3 z, float b, float* y, long yn, lo
     f32x4 v = *reinterpret_cast<const f32x4*>(x.p + n * x.sn + yy * x.sh + xx * x.sw + c) * a;
     if (z.p) v += *reinterpret_cast<const f32x4*>(z.p + n * z.sn + yy * z.sh + xx * z.sw + c) * b;
     *reinterpret_cast<f32x4*>(y + n * yn + yy * yh + xx * yw + c) = v;
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
   }
+  if (yamax) wave_raise_amax(m, yamax);
 }
 
 __global__ void dact_kernel(V3 x, V3 s, int act, float* y, long yn, long yh, long yw, int N, int H, int W, int C4) {
@@ -625,13 +637,14 @@ extern "C" int mt_sumpool(const mt_view* dxup, const mt_view* dx, int32_t ups, v
   return mt_check_launch("mt_sumpool");
 }
 
-extern "C" int mt_axpby(const mt_view* x, float a, const mt_view* z, float b, const mt_view* y, void* stream) {
+extern "C" int mt_axpby(const mt_view* x, float a, const mt_view* z, float b, const mt_view* y, float* y_amax,
+                        void* stream) {
   MT_REQUIRE(mt_view_flat(x) && mt_view_flat(y) && same_geom(x, y) && x->C >= y->C, "mt_axpby: bad views");
   if (z && z->p) MT_REQUIRE(mt_view_flat(z) && same_geom(z, y) && z->C >= y->C, "mt_axpby: bad z view");
   const long total = (long)y->N * y->H * y->W * (y->C / 4);
   hipLaunchKernelGGL(axpby_kernel, dim3(mt_grid_1d(total, 256)), dim3(256), 0, S_(stream), v3(x), a,
                      v3(z && z->p ? z : nullptr), b, y->p, (long)y->sn, (long)y->sh, (long)y->sw, y->N, y->H, y->W,
-                     y->C / 4);
+                     y->C / 4, y_amax);
   return mt_check_launch("mt_axpby");
 }
 

@@ -562,7 +562,23 @@ def _splits(blocks_base, pixels):
     return max(1, min(s, 512))
 
 
-def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_amax=None, x_amax=None, sub_blocks=None):
+INPLACE_GRADS = os.environ.get('MT355_INPLACE_GRADS', '1') != '0'
+
+
+def inplace_grad(p):
+    """The flat-buffer gradient window of parameter ``p`` (FlatAdam tags them) or None.
+    With a window the weight-gradient reduce ADDS into it and the autograd Function returns
+    None for that parameter: no temporary, no AccumulateGrad add launch per parameter.
+    (torch.autograd.grad() on such a model sees no gradient for conv parameters:
+    MT355_INPLACE_GRADS=0 restores returned gradients.)"""
+    g = getattr(p, 'grad', None) if p is not None else None
+    if INPLACE_GRADS and g is not None and getattr(g, '_mt_flat', False) and g.is_contiguous():
+        return g
+    return None
+
+
+def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_amax=None, x_amax=None, sub_blocks=None,
+                         grad_w=None, grad_b=None):
     """(dW, db) of one layer.  dz: (N,Ho,Wo,CoP) gradient wrt the layer's
     pre-activation output; xin_view: mt_view of the layer's input.
 
@@ -570,7 +586,10 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     Conv2d layers that read channel prefixes of the same input and whose output
     gradients sit side by side in ``dz`` (the four growth convs of a dense
     block): the launch forms the whole (sum cout_i) x (max cin_i) product and
-    every layer takes its sub-block of the slabs.  Returns [(dW_i, db_i), ...]."""
+    every layer takes its sub-block of the slabs.  Returns [(dW_i, db_i), ...].
+
+    ``grad_w`` / ``grad_b`` (sub_blocks: a 5th / 6th tuple entry): gradient buffers to ADD into
+    (see inplace_grad); the corresponding return value is then None."""
     dzv = view_of(dz)
     if spec.kind == 'c':
         dv, gv, a, b = dzv, xin_view, spec.cout, spec.cin
@@ -625,31 +644,36 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
         kname = f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else (1 if rows5 else "3+2")},{_HTAG[prec]}>'
     else:
         kname = ('wgrad_kernel' if prec == 'f32' else 'wgrad_split_kernel') + f'<{wcfg}{_KTAG[prec]}>'
-    useful = spec.cin * spec.cout if sub_blocks is None else sum(ca * cb for _, ca, cb, _ in sub_blocks)
+    useful = spec.cin * spec.cout if sub_blocks is None else sum(sb[1] * sb[2] for sb in sub_blocks)
     with _Prof(kname, 2.0 * pixels * useful * t):     # (algorithmic FLOP: only the sub-blocks that are kept)
         L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
     if sub_blocks is not None:
         assert spec.kind == 'c' and (fused_bias or not need_bias)
         outs = []
-        for a0, ca, cb, wi in sub_blocks:
-            dwi = torch.empty_like(wi)
-            dbi = torch.empty((ca,), device=wi.device, dtype=torch.float32) if need_bias else None
+        for sb in sub_blocks:
+            a0, ca, cb, wi = sb[:4]
+            gwi, gbi = (sb[4], sb[5]) if len(sb) > 4 else (None, None)
+            inplace = gwi is not None and (gbi is not None or not need_bias)
+            dwi = gwi if inplace else torch.empty_like(wi)
+            dbi = (gbi if inplace else torch.empty((ca,), device=wi.device, dtype=torch.float32)) if need_bias else None
             # sub-block rows a0.. of every slab (the slab stride stays that of the whole launch)
             L.call('mt_wgrad_reduce', C.c_void_p(slabs.data_ptr() + 4 * a0 * ts * bp), d.splits, ap, t, ts, bp,
-                   L.ptr(dwi), ca, cb, cb * t, t, 1, 0, scale, L.ptr(dbi) if fused_bias else None, L.stream_ptr())
-            outs.append((dwi, dbi))
+                   L.ptr(dwi), ca, cb, cb * t, t, 1, 1 if inplace else 0, scale, L.ptr(dbi) if fused_bias else None,
+                   L.stream_ptr())
+            outs.append((None, None) if inplace else (dwi, dbi))
         return outs
-    dw = torch.empty_like(w)
-    db = torch.empty((spec.cout,), device=w.device, dtype=torch.float32) if need_bias else None
+    inplace = grad_w is not None and (grad_b is not None or not need_bias) and (fused_bias or not need_bias or scale == 1.0)
+    dw = grad_w if inplace else torch.empty_like(w)
+    db = (grad_b if inplace else torch.empty((spec.cout,), device=w.device, dtype=torch.float32)) if need_bias else None
     # both Conv2d (O,I,k,k) and ConvTranspose2d (I,O,k,k): a = dim 0, b = dim 1
-    L.call('mt_wgrad_reduce', L.ptr(slabs), d.splits, ap, t, ts, bp, L.ptr(dw), a, b, b * t, t, 1, 0, scale,
+    L.call('mt_wgrad_reduce', L.ptr(slabs), d.splits, ap, t, ts, bp, L.ptr(dw), a, b, b * t, t, 1, 1 if inplace else 0, scale,
            L.ptr(db) if fused_bias else None, L.stream_ptr())
     if need_bias and not fused_bias:
         ws = torch.empty((256 * dz.shape[3],), device=w.device, dtype=torch.float32)
-        L.call('mt_bias_grad', C.byref(dzv), L.ptr(db), spec.cout, L.ptr(ws), 0, L.stream_ptr())
+        L.call('mt_bias_grad', C.byref(dzv), L.ptr(db), spec.cout, L.ptr(ws), 1 if inplace else 0, L.stream_ptr())
         if scale != 1.0:
             db.mul_(scale)
-    return dw, db
+    return (None, None) if inplace else (dw, db)
 
 
 def dact_(g, saved, act):
@@ -705,7 +729,8 @@ class ConvStackFn(torch.autograd.Function):
             sp, w = specs[i], params[2 * i]
             xin = acts[i]
             xin_view = swap_view(xin, sp.swap_groups) if sp.swap_groups else view_of(xin)
-            dw, db = conv_backward_weight(sp, dz, xin_view, w)
+            dw, db = conv_backward_weight(sp, dz, xin_view, w, grad_w=inplace_grad(w),
+                                          grad_b=inplace_grad(params[2 * i + 1]))
             grads[2 * i], grads[2 * i + 1] = dw, db
             if i == 0 and not need_x:
                 dz = None

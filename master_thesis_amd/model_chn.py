@@ -27,9 +27,12 @@ from .utils import LossesUtils, take
 LRELU, NONE = L.ACT_LRELU, L.ACT_NONE
 
 
-def _axpby(x, a, z, b, out):
+def _axpby(x, a, z, b, out, amax=None):
+    """out = a*x + b*z; ``amax``: optional device scalar the launch raises to max|out|.  (Not used
+    by default: a streaming kernel's waves all finish together, and their atomics on one scalar cost
+    more than the separate mt_absmax pass -- measured +10 ms per CHN step.)"""
     L.call('mt_axpby', C.byref(E.view_of(x)), a, C.byref(E.view_of(z)) if z is not None else None, b,
-           C.byref(E.view_of(out)), L.stream_ptr())
+           C.byref(E.view_of(out)), L.ptr(amax), L.stream_ptr())
     return out
 
 
@@ -132,7 +135,9 @@ class RRDBNetFn(torch.autograd.Function):
         _axpby(d_rdb, 0.2 * s_rdb, d_rdb, 0.0, dzb[..., :nf])
         if f16:
             E.absmax_into(dzb[..., :nf], dba)
-        dw, db = E.conv_backward_weight(spec(cw, nf), dzb[..., :nf], E.view_of(buf), W[5], x_amax=buf_amax, dz_amax=dba)
+        Bi = [None] + [P[f'{key}conv{i}.bias'] for i in (1, 2, 3, 4, 5)]
+        dw, db = E.conv_backward_weight(spec(cw, nf), dzb[..., :nf], E.view_of(buf), W[5], x_amax=buf_amax, dz_amax=dba,
+                                        grad_w=E.inplace_grad(W[5]), grad_b=E.inplace_grad(Bi[5]))
         G[f'{key}conv5.weight'], G[f'{key}conv5.bias'] = dw, db
         for i in (4, 3, 2, 1):
             kk = nf + (4 - i) * gc                  # channels of [dz5 .. dz(i+1)]
@@ -146,7 +151,8 @@ class RRDBNetFn(torch.autograd.Function):
                              packed=E.pack_stacked_bwd([W[l] for l in (5, 4, 3, 2, 1)], 0, nf, prec, wa),
                              res=d_rdb, beta=s_rdb)
         # the four growth convs: one weight-gradient launch (dz4..dz1 are adjacent, conv_i reads buf[:c0_i])
-        subs = [((4 - i) * gc, gc, nf + (i - 1) * gc, W[i]) for i in (1, 2, 3, 4)]
+        subs = [((4 - i) * gc, gc, nf + (i - 1) * gc, W[i], E.inplace_grad(W[i]), E.inplace_grad(Bi[i]))
+                for i in (1, 2, 3, 4)]
         res = E.conv_backward_weight(spec(nf + 3 * gc, 4 * gc), dzb[..., nf: cw], E.view_of(buf[..., :nf + 3 * gc]), W[1],
                                      x_amax=buf_amax, dz_amax=dba, sub_blocks=subs)
         for i, (dwi, dbi) in zip((1, 2, 3, 4), res):
@@ -173,7 +179,8 @@ class RRDBNetFn(torch.autograd.Function):
 
         def wgrad(key, sp, dz, xin, scale=1.0, x_amax=None, dz_amax=None):
             dw, db = E.conv_backward_weight(sp, dz, E.view_of(xin), P[key + '.weight'], scale=scale, x_amax=x_amax,
-                                            dz_amax=dz_amax)
+                                            dz_amax=dz_amax, grad_w=E.inplace_grad(P[key + '.weight']),
+                                            grad_b=E.inplace_grad(P[key + '.bias']))
             G[key + '.weight'], G[key + '.bias'] = dw, db
 
         def bdata(key, sp, dz, dx, **kw):

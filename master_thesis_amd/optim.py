@@ -31,10 +31,18 @@ class FlatAdam(torch.optim.Optimizer):
                 k = p.numel()
                 self.flat_p[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat_p[off:off + k].view(p.shape)
-                p.grad = self.flat_g[off:off + k].view(p.shape)
+                p.grad = self._grad_view(off, k, p.shape)
                 self._slices.append((off, k))
                 off += k
         E.bump_weight_epoch()
+
+    def _grad_view(self, off, k, shape):
+        """A parameter's gradient = a window of the flat buffer.  The tag tells the conv engine's
+        backward that it may ADD a weight / bias gradient straight into it (and hand autograd None)
+        instead of returning a temporary for AccumulateGrad to add."""
+        g = self.flat_g[off:off + k].view(shape)
+        g._mt_flat = True
+        return g
 
     def zero_grad(self, set_to_none=False):
         """Gradients stay views of the flat buffer (autograd accumulates in
@@ -42,17 +50,17 @@ class FlatAdam(torch.optim.Optimizer):
         self.flat_g.zero_()
         for p, (off, k) in zip(self._plist, self._slices):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
-                p.grad = self.flat_g[off:off + k].view(p.shape)
+                p.grad = self._grad_view(off, k, p.shape)
 
     def _gather_foreign_grads(self):
         for p, (off, k) in zip(self._plist, self._slices):
             want = self.flat_g.data_ptr() + 4 * off
             if p.grad is None:
                 self.flat_g[off:off + k].zero_()
-                p.grad = self.flat_g[off:off + k].view(p.shape)
+                p.grad = self._grad_view(off, k, p.shape)
             elif p.grad.data_ptr() != want:
                 self.flat_g[off:off + k].copy_(p.grad.reshape(-1))
-                p.grad = self.flat_g[off:off + k].view(p.shape)
+                p.grad = self._grad_view(off, k, p.shape)
 
     @torch.no_grad()
     def step(self, closure=None):
