@@ -157,6 +157,17 @@ int mt_wgrad_reduce(const float* slabs, int32_t splits, int32_t AP, int32_t T,
                     int32_t TS, int32_t BP, float* dst, int32_t A, int32_t B,
                     int64_t sa, int64_t sb, int64_t st, int32_t accumulate,
                     float scale, float* db, void* stream);
+/* The same for up to 8 sub-blocks of one launch's slabs (row ranges [a0, a0 + A) x [0, B):
+ * the layers that shared a weight-gradient launch) in ONE reduce launch. */
+typedef struct {
+  int32_t a0, A, B;
+  int64_t sa, sb, st;
+  float* dst;
+  float* db;           /* bias sums of rows a0.. (slabs with the extra tap) or NULL */
+} mt_reduce_sub;
+int mt_wgrad_reduce_multi(const float* slabs, int32_t splits, int32_t AP, int32_t T,
+                          int32_t TS, int32_t BP, const mt_reduce_sub* subs,
+                          int32_t nsub, int32_t accumulate, float scale, void* stream);
 /* db[c] (+)= sum_pixels D[n,y,x,c], c < C (ws: >= 256*D.C floats) */
 int mt_bias_grad(const mt_view* d, float* db, int32_t C, float* ws,
                  int32_t accumulate, void* stream);

@@ -55,6 +55,11 @@ class PackJob(C.Structure):
                 ('frag_order', i32)]
 
 
+class ReduceSub(C.Structure):
+    _fields_ = [('a0', i32), ('A', i32), ('B', i32), ('sa', i64), ('sb', i64), ('st', i64),
+                ('dst', C.c_void_p), ('db', C.c_void_p)]
+
+
 class PackSrc(C.Structure):
     _fields_ = [('p', C.c_void_p), ('sb', i64), ('sr', i64), ('sc', i64),
                 ('sy', i64), ('sx', i64), ('C', i32), ('c_off', i32),
@@ -75,6 +80,7 @@ SIGNATURES = {
     'mt_wgrad_run': [_P(Wgrad), _vp],
     'mt_wgrad_slab_floats': [_P(Wgrad)],
     'mt_wgrad_reduce': [_vp, i32, i32, i32, i32, i32, _vp, i32, i32, i64, i64, i64, i32, f32, _vp, _vp],
+    'mt_wgrad_reduce_multi': [_vp, i32, i32, i32, i32, i32, _vp, i32, i32, f32, _vp],
     'mt_bias_grad': [_P(View), _vp, i32, _vp, i32, _vp],
     'mt_weight_pack': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, _vp],
     'mt_weight_pack_split': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp, _vp],

@@ -682,9 +682,11 @@ __global__ void weight_pack_split_kernel(const float* src, int A, int B, int T, 
 // dst[a][t][b] (+)= sum_s slabs[s][a][t][b]; 256 threads = 64 consecutive
 // elements x 4 interleaved split lanes, combined through LDS.  TS >= T is the
 // slab's tap count: tap T (column 0), when present, holds the bias sums.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int splits, int AP, int T, int TS, int BP,
-                                                           float* dst, int A, int B, long sa, long sb, long st,
-                                                           int accumulate, float scale, float* db) {
+struct ReduceSubs { mt_reduce_sub s[8]; };
+
+__device__ __forceinline__ void wgrad_reduce_body(const float* slabs, int splits, int AP, int T, int TS, int BP,
+                                                  float* dst, int A, int B, long sa, long sb, long st, int accumulate,
+                                                  float scale, float* db) {
   __shared__ float part[4][64];
   const long per = (long)AP * TS * BP;
   const long total = (long)A * TS * B;
@@ -714,6 +716,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, i
     }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, int splits, int AP, int T, int TS, int BP,
+                                                           float* dst, int A, int B, long sa, long sb, long st,
+                                                           int accumulate, float scale, float* db) {
+  wgrad_reduce_body(slabs, splits, AP, T, TS, BP, dst, A, B, sa, sb, st, accumulate, scale, db);
+}
+
+// several sub-blocks (row ranges a0.. of the same slabs) in one launch: blockIdx.y = sub-block
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const float* slabs, int splits, int AP, int T, int TS,
+                                                                 int BP, ReduceSubs subs, int accumulate, float scale) {
+  const mt_reduce_sub u = subs.s[blockIdx.y];
+  wgrad_reduce_body(slabs + (long)u.a0 * TS * BP, splits, AP, T, TS, BP, u.dst, u.A, u.B, u.sa, u.sb, u.st, accumulate,
+                    scale, u.db);
 }
 
 __global__ void bias_grad_partial_kernel(const float* d, long dsn, long dsh, long dsw, int Hd, int Wd, int CP,
@@ -882,6 +898,24 @@ extern "C" int mt_wgrad_reduce(const float* slabs, int32_t splits, int32_t AP, i
                      static_cast<hipStream_t>(stream), slabs, splits, AP, T, TS, BP, dst, A, B, (long)sa, (long)sb,
                      (long)st, accumulate, scale, db);
   return mt_check_launch("mt_wgrad_reduce");
+}
+
+extern "C" int mt_wgrad_reduce_multi(const float* slabs, int32_t splits, int32_t AP, int32_t T, int32_t TS, int32_t BP,
+                                     const mt_reduce_sub* subs, int32_t nsub, int32_t accumulate, float scale,
+                                     void* stream) {
+  MT_REQUIRE(slabs && subs && splits >= 1 && nsub >= 1 && nsub <= 8 && (TS == T || TS == T + 1),
+             "mt_wgrad_reduce_multi: bad arguments");
+  ReduceSubs rs;
+  int64_t most = 0;
+  for (int i = 0; i < nsub; ++i) {
+    const mt_reduce_sub& u = subs[i];
+    MT_REQUIRE(u.dst && u.a0 >= 0 && u.A >= 1 && u.a0 + u.A <= AP && u.B <= BP, "mt_wgrad_reduce_multi: sub-block %d", i);
+    rs.s[i] = u;
+    most = most > (int64_t)u.A * TS * u.B ? most : (int64_t)u.A * TS * u.B;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(mt_grid_1d(most, 64, 2048), nsub), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), slabs, splits, AP, T, TS, BP, rs, accumulate, scale);
+  return mt_check_launch("mt_wgrad_reduce_multi");
 }
 
 extern "C" int mt_bias_grad(const mt_view* d, float* db, int32_t C, float* ws, int32_t accumulate, void* stream) {

@@ -649,18 +649,23 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
         L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
     if sub_blocks is not None:
         assert spec.kind == 'c' and (fused_bias or not need_bias)
-        outs = []
-        for sb in sub_blocks:
+        outs, subs, keep = [], (L.ReduceSub * len(sub_blocks))(), []
+        all_inplace = None
+        for n_, sb in enumerate(sub_blocks):
             a0, ca, cb, wi = sb[:4]
             gwi, gbi = (sb[4], sb[5]) if len(sb) > 4 else (None, None)
             inplace = gwi is not None and (gbi is not None or not need_bias)
+            assert all_inplace in (None, inplace), 'sub-blocks must agree on in-place accumulation'
+            all_inplace = inplace
             dwi = gwi if inplace else torch.empty_like(wi)
             dbi = (gbi if inplace else torch.empty((ca,), device=wi.device, dtype=torch.float32)) if need_bias else None
-            # sub-block rows a0.. of every slab (the slab stride stays that of the whole launch)
-            L.call('mt_wgrad_reduce', C.c_void_p(slabs.data_ptr() + 4 * a0 * ts * bp), d.splits, ap, t, ts, bp,
-                   L.ptr(dwi), ca, cb, cb * t, t, 1, 1 if inplace else 0, scale, L.ptr(dbi) if fused_bias else None,
-                   L.stream_ptr())
+            keep += [dwi, dbi]
+            subs[n_] = L.ReduceSub(a0, ca, cb, cb * t, t, 1, dwi.data_ptr(),
+                                   dbi.data_ptr() if (fused_bias and dbi is not None) else None)
             outs.append((None, None) if inplace else (dwi, dbi))
+        # every layer's sub-block (rows a0.. of every slab) in one reduce launch
+        L.call('mt_wgrad_reduce_multi', L.ptr(slabs), d.splits, ap, t, ts, bp, subs, len(sub_blocks),
+               1 if all_inplace else 0, scale, L.stream_ptr())
         return outs
     inplace = grad_w is not None and (grad_b is not None or not need_bias) and (fused_bias or not need_bias or scale == 1.0)
     dw = grad_w if inplace else torch.empty_like(w)

@@ -42,9 +42,9 @@ def test_struct_layouts_match_the_header():
     import subprocess
     import tempfile
     from master_thesis_amd import _lib
-    src = '#include <stdio.h>\n#include "mt355.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mt_view), ' \
+    src = '#include <stdio.h>\n#include "mt355.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mt_view), ' \
           'sizeof(mt_conv), sizeof(mt_wgrad), sizeof(mt_warp_layout), sizeof(mt_pack_src), sizeof(mt_amax_seg), ' \
-          'sizeof(mt_pack_job));return 0;}\n'
+          'sizeof(mt_pack_job), sizeof(mt_reduce_sub));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, 's.c')
         open(c, 'w').write(src)
@@ -52,7 +52,7 @@ def test_struct_layouts_match_the_header():
         subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     mine = [ctypes.sizeof(t) for t in (_lib.View, _lib.Conv, _lib.Wgrad, _lib.WarpLayout, _lib.PackSrc, _lib.AmaxSeg,
-                                       _lib.PackJob)]
+                                       _lib.PackJob, _lib.ReduceSub)]
     assert sizes == mine, (sizes, mine)
 
 
