@@ -4,6 +4,7 @@
 #   <tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-chn` (DFPN cfg2 only, so per-kernel averages are those of the roofline line)
 #   <tag>_bench_under_rocprof.json the bench line printed in that run
 #   <tag>_pmc_hbm_traffic.txt      FETCH_SIZE / WRITE_SIZE (separate passes) per kernel, DFPN cfg2 step (eager) + correlation micro-bench
+#   <tag>_pmc_mfma_util.txt        matrix-pipe utilisation and sustained clock per kernel (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE)
 # usage: tools/collect_profiles.sh <tag>
 set -u
 export TMPDIR=/tmp
@@ -15,6 +16,8 @@ cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/${tag}_bench_kern
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $out/pmc_$c -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-chn --no-graph > $out/pmc_$c.json 2> $out/pmc_$c.err || echo "pmc $c failed"
 done
+# matrix-pipe utilisation: MFMA busy cycles (summed over the 1024 SIMDs) against the GPU-active cycles
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/pmc_MFMA -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-chn --no-graph > $out/pmc_MFMA.json 2> $out/pmc_MFMA.err || echo "pmc MFMA failed"
 python3 - "$out" "$tag" <<'PY'
 import csv, glob, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
@@ -46,6 +49,36 @@ with open(f'{out}/{tag}_pmc_hbm_traffic.txt', 'w') as o:
         name = k.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '').split('(')[0]
         o.write(f'{name},{n},{f:.1f},{w:.1f},{mb:.1f},{ms:.3f},{mb / ms if ms else 0:.0f}\n')
 print(open(f'{out}/{tag}_pmc_hbm_traffic.txt').read()[:3000])
+# ---- MFMA utilisation
+f = glob.glob(f'{out}/pmc_MFMA/**/*counter_collection.csv', recursive=True)
+if f:
+    busy, act, dur = collections.defaultdict(list), collections.defaultdict(list), collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        k = r['Kernel_Name']
+        if r['Counter_Name'] == 'SQ_VALU_MFMA_BUSY_CYCLES':
+            busy[k].append(float(r['Counter_Value']))
+            dur[k].append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e6)
+        elif r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
+            act[k].append(float(r['Counter_Value']))
+    rows = []
+    for k in busy:
+        b, a, ms = sum(busy[k]), sum(act.get(k, [0])), sum(dur[k])
+        if b <= 0 or a <= 0:
+            continue
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 256 CUs x 4 SIMDs = 1024 matrix pipes
+        util = b / (a / 8 * 1024)
+        clk = a / 8 / (ms * 1e-3) / 1e9
+        rows.append((b, k, len(busy[k]), ms, util, clk))
+    rows.sort(reverse=True)
+    with open(f'{out}/{tag}_pmc_mfma_util.txt', 'w') as o:
+        o.write('# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace, bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-chn --no-graph\n')
+        o.write('# mfma_util = MFMA busy cycles / (GPU-active cycles per XCD x 1024 SIMDs); clock = active cycles per XCD / duration.\n')
+        o.write('# The dense 16-bit peak (2.5 PFLOP/s) assumes util 1.0 at 2.4 GHz; on random fp16 data a pure-MFMA loop holds ~1.62 GHz (scratch/lab/mfma_peak.hip).\n')
+        o.write('kernel,launches,total_ms_under_pmc,mfma_util,clock_GHz\n')
+        for b, k, n, ms, util, clk in rows[:30]:
+            name = k.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '').split('(')[0]
+            o.write(f'{name},{n},{ms:.3f},{util:.3f},{clk:.2f}\n')
+    print(open(f'{out}/{tag}_pmc_mfma_util.txt').read())
 PY
-rm -rf $out/stats $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE
+rm -rf $out/stats $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_MFMA
 ls -la $out
