@@ -366,6 +366,110 @@ class CHN(LightningModule):
         self._log_losses(loss, loss_items, 'validation')
         return loss
 
+    # ---- test-time inpainting drivers (model_chn.py:87-254, 309-323): orchestration over the
+    # aligner and forward() above; every tensor op stays on the device, the only host reads are
+    # the hole percentages that steer the loops (as in the reference).  They work on COPIES of
+    # x and m (the reference's inpaint_ip / inpaint_cp update their arguments in place through
+    # unsqueeze views); the returned sequences are the same.
+    @staticmethod
+    def _fill_color(x):
+        return torch.as_tensor([0.485, 0.456, 0.406], dtype=torch.float32, device=x.device).view(1, 3, 1, 1)
+
+    @torch.no_grad()
+    def _align_forward(self, x_t, m_t, x_r, m_r):
+        xa, va, v_map = self.model_aligner.align(x_t.contiguous(), m_t.contiguous(), x_r.contiguous(), m_r.contiguous())
+        y_hat, y_hat_comp = self(x_t.contiguous(), (1 - m_t).contiguous(), xa, va, v_map)
+        return y_hat_comp, v_map
+
+    @torch.no_grad()
+    def inpaint_ff(self, x, m, s=1, D=20, e=1):
+        """Frame-by-Frame algorithm, model_chn.py:87-133.  x (3,F,H,W), m (1,F,H,W) -> (3,F,H,W)."""
+        fill = CHN._fill_color(x)
+        y_inpainted = torch.zeros_like(x)
+        for t in range(x.size(1)):
+            x_target, m_target = x[:, t].unsqueeze(0), m[:, t].unsqueeze(0)
+            y_hat_comp, inp_per = None, 0
+            t_candidates = CHN.get_indexes_ff(t, x.size(1), s=s, D=D)
+            while (len(t_candidates) > 0 and inp_per > e) or y_hat_comp is None:
+                r_list = [t_candidates.pop(0)]
+                y_hat_comp, v_map = self._align_forward(x_target, m_target, x[:, r_list].unsqueeze(0),
+                                                        m[:, r_list].unsqueeze(0))
+                m_target = m_target - v_map[:, :, 0]
+                x_target = (1 - m_target) * y_hat_comp[:, :, 0] + m_target.repeat(1, 3, 1, 1) * fill
+                inp_per = float(torch.sum(m_target) * 100 / m_target.numel())
+            y_inpainted[:, t] = y_hat_comp[:, :, 0]
+        return y_inpainted
+
+    @torch.no_grad()
+    def inpaint_ip(self, x, m, s=1, D=20, e=1):
+        """Inpaint-and-Propagate algorithm, model_chn.py:135-190."""
+        fill = CHN._fill_color(x)
+        y_inpainted, m_inpainted = x.clone().unsqueeze(0), m.clone().unsqueeze(0)
+        t_list = sorted(list(range(x.size(1))), key=lambda xi: abs(xi - x.size(1) // 2))
+        for t in t_list:
+            t_candidates = CHN.get_indexes_ip(t, t_list, s, D)
+            y_hat_comp, inp_per = None, 0
+            while (len(t_candidates) > 0 and inp_per > e) or y_hat_comp is None:
+                r_list = [t_candidates.pop(0)]
+                y_hat_comp, v_map = self._align_forward(y_inpainted[:, :, t], m_inpainted[:, :, t],
+                                                        y_inpainted[:, :, r_list], m_inpainted[:, :, r_list])
+                m_inpainted[:, :, t] = m_inpainted[:, :, t] - v_map[:, :, 0]
+                y_inpainted[:, :, t] = (1 - m_inpainted[:, :, t]) * y_hat_comp[:, :, 0] + \
+                    m_inpainted[:, :, t].repeat(1, 3, 1, 1) * fill
+                inp_per = float(torch.sum(m_inpainted[:, :, t]) * 100 / m_inpainted[:, :, t].numel())
+            m_inpainted[:, :, t] = 0
+            y_inpainted[:, :, t] = y_hat_comp[:, :, 0]
+        return y_inpainted[0]
+
+    @torch.no_grad()
+    def inpaint_cp(self, x, m, N=20, s=1, e=1):
+        """Copy-and-Propagate algorithm, model_chn.py:192-254."""
+        fill = CHN._fill_color(x)
+        y_inpainted, m_inpainted = x.clone().unsqueeze(0), m.clone().unsqueeze(0)
+        for i in range(N):
+            t_list = [t for t in range(y_inpainted.size(2)) if (t // s) % (s if s > 1 else 2) == i % 2]
+            for t in t_list:
+                if float(m_inpainted[:, :, t].sum()) == 0:
+                    continue
+                for delta_t in [-s, s]:
+                    if not 0 <= t + delta_t < y_inpainted.size(2):
+                        continue
+                    r_list = [t + delta_t]
+                    y_hat_comp, v_map = self._align_forward(y_inpainted[:, :, t], m_inpainted[:, :, t],
+                                                            y_inpainted[:, :, r_list], m_inpainted[:, :, r_list])
+                    m_inpainted[:, :, t] = m_inpainted[:, :, t] - v_map[:, :, 0]
+                    y_inpainted[:, :, t] = (1 - m_inpainted[:, :, t]) * y_hat_comp[:, :, 0] + \
+                        m_inpainted[:, :, t].repeat(1, 3, 1, 1) * fill
+                    inp_per = float(torch.sum(m_inpainted[:, :, t]) * 100 / m_inpainted[:, :, t].numel())
+                    if inp_per < e or i >= N - 2:
+                        m_inpainted[:, :, t] = 0
+                        y_inpainted[:, :, t] = y_hat_comp[:, :, 0]
+        return y_inpainted[0]
+
+    def test_step(self, batch, batch_idx):
+        """model_chn.py:309-323: the three drivers on the first clip of the batch.  The reference
+        writes .avi files through cv2 (out of scope); the sequences are returned instead."""
+        (x, m), y, info = batch
+        return {'ff': self.inpaint_ff(x[0], m[0]), 'ip': self.inpaint_ip(x[0], m[0]),
+                'cp': self.inpaint_cp(x[0], m[0])}
+
+    @staticmethod
+    def get_indexes_ff(t, max_t, s, D):
+        """model_chn.py:459-481."""
+        ref_candidates = list(range(max_t))
+        ref_candidates.pop(t)
+        ref_candidates_dist = list(map(lambda x: abs(x - t), ref_candidates))
+        ref_candidates_sorted = [r[1] for r in sorted(zip(ref_candidates_dist, ref_candidates))]
+        return list(filter(lambda x: abs(x - t) <= D and abs(x - t) % s == 0, ref_candidates_sorted))
+
+    @staticmethod
+    def get_indexes_ip(t, t_list, s, D):
+        """model_chn.py:483-503."""
+        t_list_inpainted = list(reversed(t_list[:t_list.index(t)]))
+        t_list_ff = CHN.get_indexes_ff(t, len(t_list), s, D)
+        t_list_ff = [t_item for t_item in t_list_ff if t_item not in t_list_inpainted]
+        return t_list_inpainted + t_list_ff
+
     def compute_loss(self, y_target, v_target, y_hat, y_hat_comp, v_map):
         """model_chn.py:324-376.  The reference passes 5-D tensors to the Sobel
         conv (:371-373) and raises for more than one reference frame; here the

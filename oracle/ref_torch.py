@@ -478,3 +478,97 @@ def cpn_warp(x_r, m_r, m_t, theta):
     va = unfold_frames((F.grid_sample(1 - fold_frames(m_r), grid,
                                       align_corners=False) > 0.5).float(), b)
     return xa, va, (va - (1 - m_t.unsqueeze(2))).clamp(0, 1)
+
+
+# --------------------------------------------------------------------------
+# test-time inpainting drivers: orchestration over align + forward
+# --------------------------------------------------------------------------
+def get_indexes_ff(t, max_t, s, D):
+    """CHN.get_indexes_ff, model_chn.py:459-481: the other frames by distance to
+    ``t`` (ties: lower index first), within D and on the s grid."""
+    cand = [r for r in range(max_t) if r != t]
+    cand = [r for _, r in sorted((abs(r - t), r) for r in cand)]
+    return [r for r in cand if abs(r - t) <= D and abs(r - t) % s == 0]
+
+
+def get_indexes_ip(t, t_list, s, D):
+    """CHN.get_indexes_ip, model_chn.py:483-503: frames already inpainted (latest
+    first), then the frame-by-frame candidates that are not among them."""
+    done = list(reversed(t_list[:t_list.index(t)]))
+    return done + [r for r in get_indexes_ff(t, len(t_list), s, D) if r not in done]
+
+
+FILL_COLOR = (0.485, 0.456, 0.406)
+
+
+def _fill(x):
+    return torch.tensor(FILL_COLOR, dtype=x.dtype).view(1, 3, 1, 1)
+
+
+def _align_forward(sd, x_t, m_t, x_r, m_r, prefix, aligner_prefix, nb):
+    xa, va, v_map = dfpn_align(sd, x_t, m_t, x_r, m_r, prefix + aligner_prefix)
+    y_hat, y_comp = chn_forward(sd, x_t, 1 - m_t, xa, va, v_map, prefix, nb)
+    return y_comp, v_map
+
+
+def inpaint_ff(sd, x, m, s=1, D=20, e=1, prefix='', aligner_prefix='model_aligner.', nb=20):
+    """CHN.inpaint_ff (Frame-by-Frame), model_chn.py:87-133.  x (3,F,H,W), m (1,F,H,W)."""
+    out = torch.zeros_like(x)
+    for t in range(x.shape[1]):
+        x_t, m_t = x[:, t].unsqueeze(0), m[:, t].unsqueeze(0)
+        y_comp, per = None, 0
+        cand = get_indexes_ff(t, x.shape[1], s, D)
+        while (len(cand) > 0 and per > e) or y_comp is None:
+            r = [cand.pop(0)]
+            y_comp, v_map = _align_forward(sd, x_t, m_t, x[:, r].unsqueeze(0), m[:, r].unsqueeze(0), prefix,
+                                           aligner_prefix, nb)
+            m_t = m_t - v_map[:, :, 0]
+            x_t = (1 - m_t) * y_comp[:, :, 0] + m_t.repeat(1, 3, 1, 1) * _fill(x)
+            per = float(m_t.sum() * 100 / m_t.numel())
+        out[:, t] = y_comp[:, :, 0]
+    return out
+
+
+def inpaint_ip(sd, x, m, s=1, D=20, e=1, prefix='', aligner_prefix='model_aligner.', nb=20):
+    """CHN.inpaint_ip (Inpaint and Propagate), model_chn.py:135-190 (on copies: the
+    reference updates its arguments in place through unsqueeze views)."""
+    y, mm = x.clone().unsqueeze(0), m.clone().unsqueeze(0)
+    f = x.shape[1]
+    t_list = sorted(range(f), key=lambda i: abs(i - f // 2))
+    for t in t_list:
+        cand = get_indexes_ip(t, t_list, s, D)
+        y_comp, per = None, 0
+        while (len(cand) > 0 and per > e) or y_comp is None:
+            r = [cand.pop(0)]
+            y_comp, v_map = _align_forward(sd, y[:, :, t], mm[:, :, t], y[:, :, r], mm[:, :, r], prefix,
+                                           aligner_prefix, nb)
+            mm[:, :, t] = mm[:, :, t] - v_map[:, :, 0]
+            y[:, :, t] = (1 - mm[:, :, t]) * y_comp[:, :, 0] + mm[:, :, t].repeat(1, 3, 1, 1) * _fill(x)
+            per = float(mm[:, :, t].sum() * 100 / mm[:, :, t].numel())
+        mm[:, :, t] = 0
+        y[:, :, t] = y_comp[:, :, 0]
+    return y[0]
+
+
+def inpaint_cp(sd, x, m, N=20, s=1, e=1, prefix='', aligner_prefix='model_aligner.', nb=20):
+    """CHN.inpaint_cp (Copy and Propagate), model_chn.py:192-254 (on copies)."""
+    y, mm = x.clone().unsqueeze(0), m.clone().unsqueeze(0)
+    f = x.shape[1]
+    for i in range(N):
+        t_list = [t for t in range(f) if (t // s) % (s if s > 1 else 2) == i % 2]
+        for t in t_list:
+            if float(mm[:, :, t].sum()) == 0:
+                continue
+            for dt in (-s, s):
+                if not 0 <= t + dt < f:
+                    continue
+                r = [t + dt]
+                y_comp, v_map = _align_forward(sd, y[:, :, t], mm[:, :, t], y[:, :, r], mm[:, :, r], prefix,
+                                               aligner_prefix, nb)
+                mm[:, :, t] = mm[:, :, t] - v_map[:, :, 0]
+                y[:, :, t] = (1 - mm[:, :, t]) * y_comp[:, :, 0] + mm[:, :, t].repeat(1, 3, 1, 1) * _fill(x)
+                per = float(mm[:, :, t].sum() * 100 / mm[:, :, t].numel())
+                if per < e or i >= N - 2:
+                    mm[:, :, t] = 0
+                    y[:, :, t] = y_comp[:, :, 0]
+    return y[0]

@@ -271,8 +271,27 @@ def g11_cpn_warp():
     save('g11_cpn_warp', theta=theta, x_aligned=xa, v_aligned=va, v_maps=vmaps)
 
 
+def g12_inpaint():
+    """The three test-time drivers of CHN (model_chn.py:87-254) on a 4-frame 64x64 clip
+    (inpaint_cp with N = 2 iterations), and the index helpers."""
+    model = ref_chn()
+    (x, m), y, info = S.synthetic_batch(1, 4, 64, 64, seed=12)
+    res = {}
+    with torch.no_grad():
+        res['ff'] = model.inpaint_ff(x[0].clone(), m[0].clone())
+        res['ip'] = model.inpaint_ip(x[0].clone(), m[0].clone())
+        res['cp'] = model.inpaint_cp(x[0].clone(), m[0].clone(), N=2)
+    C = mt.CHN
+    res['idx_ff'] = np.array([C.get_indexes_ff(t, 7, s, D) + [-1] * 7 for t in (0, 3, 6) for s, D in ((1, 20), (2, 4))],
+                             dtype=object).tolist() and \
+        np.array([(C.get_indexes_ff(t, 7, s, D) + [-1] * 7)[:7] for t in (0, 3, 6) for s, D in ((1, 20), (2, 4))])
+    tl = sorted(range(7), key=lambda i: abs(i - 3))
+    res['idx_ip'] = np.array([(C.get_indexes_ip(t, tl, 1, 20) + [-1] * 7)[:7] for t in tl])
+    save('g12_inpaint', **res)
+
+
 ALL = [g1_corr, g2_warp, g3_resize, g4_modules, g5_dfpn_fwd, g6_dfpn_loss,
-       g7_rrdbnet, g8_chn_loss, g9_grads, g10_vgg, g11_cpn_warp]
+       g7_rrdbnet, g8_chn_loss, g9_grads, g10_vgg, g11_cpn_warp, g12_inpaint]
 
 if __name__ == '__main__':
     torch.set_num_threads(os.cpu_count())

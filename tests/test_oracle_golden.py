@@ -193,3 +193,18 @@ def test_g11_cpn_warp(golden):
     xa, va, vm = O.cpn_warp(x, m, m_t, torch.from_numpy(g['theta']))
     close(xa, g['x_aligned'])
     assert np.array_equal(va.numpy(), g['v_aligned']) and np.array_equal(vm.numpy(), g['v_maps'])
+
+
+def test_g12_inpainting_drivers(golden, chn_sd):
+    """The frame-by-frame / inpaint-and-propagate / copy-and-propagate drivers and their index
+    helpers against the reference's own runs (model_chn.py:87-254, 459-503)."""
+    g = golden('g12_inpaint')
+    for i, (t, (s, d)) in enumerate((t, sd) for t in (0, 3, 6) for sd in ((1, 20), (2, 4))):
+        assert (O.get_indexes_ff(t, 7, s, d) + [-1] * 7)[:7] == list(g['idx_ff'][i])
+    tl = sorted(range(7), key=lambda i: abs(i - 3))
+    for i, t in enumerate(tl):
+        assert (O.get_indexes_ip(t, tl, 1, 20) + [-1] * 7)[:7] == list(g['idx_ip'][i])
+    (x, m), y, info = S.synthetic_batch(1, 4, 64, 64, seed=12)
+    with torch.no_grad():
+        close(O.inpaint_ff(chn_sd, x[0], m[0]), g['ff'], rtol=2e-3)
+        close(O.inpaint_cp(chn_sd, x[0], m[0], N=2), g['cp'], rtol=2e-3)
