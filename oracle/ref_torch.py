@@ -572,3 +572,40 @@ def inpaint_cp(sd, x, m, N=20, s=1, e=1, prefix='', aligner_prefix='model_aligne
                     mm[:, :, t] = 0
                     y[:, :, t] = y_comp[:, :, 0]
     return y[0]
+
+
+# --------------------------------------------------------------------------
+# CPN aligner networks, model_cpn.py:31-91, 121-174
+# --------------------------------------------------------------------------
+CPN_ENC = (('conv12', 2, 2), ('conv2', 1, 1), ('conv23', 2, 1), ('conv3', 1, 1), ('conv34', 2, 1), ('conv4a', 1, 1),
+           ('conv4b', 1, 1))          # (name, stride, padding); all followed by ReLU
+
+
+def cpn_a_encoder(sd, x, m, prefix='A_Encoder.'):
+    """A_Encoder.forward, model_cpn.py:138-151: normalise, append the mask, bilinear to 224 x 224, 7 conv+ReLU."""
+    f = (x - sd[prefix + 'mean']) / sd[prefix + 'std']
+    y = F.interpolate(torch.cat([f, m], dim=1), size=(224, 224), mode='bilinear', align_corners=False)
+    for name, stride, pad in CPN_ENC:
+        y = F.relu(F.conv2d(y, sd[f'{prefix}{name}.conv.0.weight'], sd[f'{prefix}{name}.conv.0.bias'], stride=stride,
+                            padding=pad))
+    return y
+
+
+def cpn_a_regressor(sd, f1, f2, prefix='A_Regressor.'):
+    """A_Regressor.forward, model_cpn.py:164-174 (conv5a / conv5b are applied twice; conv6a / conv6b
+    are never used)."""
+    y = torch.cat([f1, f2], dim=1)
+    for name, stride in (('conv45', 2), ('conv5a', 1), ('conv5b', 1), ('conv56', 2), ('conv5a', 1), ('conv5b', 1)):
+        y = F.relu(F.conv2d(y, sd[f'{prefix}{name}.conv.0.weight'], sd[f'{prefix}{name}.conv.0.bias'], stride=stride,
+                            padding=1))
+    y = F.avg_pool2d(y, y.shape[2]).view(-1, y.shape[1])
+    return F.linear(y, sd[prefix + 'fc.weight'], sd[prefix + 'fc.bias']).view(-1, 2, 3)
+
+
+def cpn_align(sd, x_t, m_t, x_r, m_r):
+    """CPN.align, model_cpn.py:31-91."""
+    b, c, r, h, w = x_r.shape
+    ft = cpn_a_encoder(sd, x_t, m_t)
+    fr = cpn_a_encoder(sd, fold_frames(x_r), fold_frames(m_r))
+    theta = cpn_a_regressor(sd, ft.unsqueeze(1).repeat(1, r, 1, 1, 1).reshape(-1, *ft.shape[1:]), fr)
+    return cpn_warp(x_r, m_r, m_t, theta) + (theta,)

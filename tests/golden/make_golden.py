@@ -290,8 +290,27 @@ def g12_inpaint():
     save('g12_inpaint', **res)
 
 
+def g13_cpn_align():
+    """CPN.align with its aligner networks (A_Encoder + A_Regressor, model_cpn.py:31-91, 121-174)."""
+    model = mt.CPN()
+    missing, unexpected = model.load_state_dict(S.cpn_state_dict(), strict=False)
+    assert not unexpected and all(not k.startswith('A_') for k in missing), (missing, unexpected)
+    model.eval()
+    b, r, h, w = 2, 2, 64, 96
+    x_t = S.uniform('g13.xt', (b, 3, h, w))
+    m_t = (S.uniform('g13.mt', (b, 1, h, w)) > 0.8).float()
+    x_r = S.uniform('g13.xr', (b, 3, r, h, w))
+    m_r = (S.uniform('g13.mr', (b, 1, r, h, w)) > 0.8).float()
+    with torch.no_grad():
+        ft = model.A_Encoder(x_t, m_t)
+        fr = model.A_Encoder(x_r.transpose(1, 2).reshape(-1, 3, h, w), m_r.transpose(1, 2).reshape(-1, 1, h, w))
+        theta = model.A_Regressor(ft.unsqueeze(1).repeat(1, r, 1, 1, 1).reshape(-1, *ft.shape[1:]), fr)
+        xa, va, vm = model.align(x_t, m_t, x_r, m_r)
+    save('g13_cpn_align', feat_t=ft[:, ::16, ::4, ::4], theta=theta, x_aligned=xa, v_aligned=va, v_maps=vm)
+
+
 ALL = [g1_corr, g2_warp, g3_resize, g4_modules, g5_dfpn_fwd, g6_dfpn_loss,
-       g7_rrdbnet, g8_chn_loss, g9_grads, g10_vgg, g11_cpn_warp, g12_inpaint]
+       g7_rrdbnet, g8_chn_loss, g9_grads, g10_vgg, g11_cpn_warp, g12_inpaint, g13_cpn_align]
 
 if __name__ == '__main__':
     torch.set_num_threads(os.cpu_count())

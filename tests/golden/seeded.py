@@ -93,6 +93,28 @@ def chn_shapes(prefix='', nb=20):
     return s
 
 
+CPN_ENC = (('conv12', 4, 64, 5), ('conv2', 64, 64, 3), ('conv23', 64, 128, 3), ('conv3', 128, 128, 3),
+           ('conv34', 128, 256, 3), ('conv4a', 256, 256, 3), ('conv4b', 256, 256, 3))
+CPN_REG = (('conv45', 512, 512, 3), ('conv5a', 512, 512, 3), ('conv5b', 512, 512, 3), ('conv56', 512, 512, 3),
+           ('conv6a', 512, 512, 3), ('conv6b', 512, 512, 3))
+
+
+def cpn_state_dict(seed=0):
+    """Seeded weights of the two ALIGNER networks of CPN (A_Encoder, A_Regressor, model_cpn.py:121-174).
+    The regressor head is shrunk towards the identity transform so that the warp samples inside the frames."""
+    sd = {}
+    for mod, layers in (('A_Encoder', CPN_ENC), ('A_Regressor', CPN_REG)):
+        for name, cin, cout, k in layers:
+            bound = float(np.sqrt(6.0 / (cin * k * k)))
+            sd[f'{mod}.{name}.conv.0.weight'] = uniform(f'cpn.{mod}.{name}.w', (cout, cin, k, k), -bound, bound, seed)
+            sd[f'{mod}.{name}.conv.0.bias'] = uniform(f'cpn.{mod}.{name}.b', (cout,), -0.1, 0.1, seed)
+    sd['A_Regressor.fc.weight'] = uniform('cpn.fc.w', (6, 512), -1, 1, seed) * 2e-3
+    sd['A_Regressor.fc.bias'] = torch.tensor([1.0, 0.0, 0.0, 0.0, 1.0, 0.0]) + uniform('cpn.fc.b', (6,), -0.05, 0.05, seed)
+    sd['A_Encoder.mean'] = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    sd['A_Encoder.std'] = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return sd
+
+
 def _canonical(name):
     # The reference registers the SAME VGG module under several names
     # (model_vgg, corr.model_vgg, model_aligner.model_vgg, ...): key the draw on

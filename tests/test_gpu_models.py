@@ -387,3 +387,34 @@ def test_g12_inpainting_drivers(golden, chn):
         assert float((d > 2e-2).float().mean()) < 2e-2, (k, float((d > 2e-2).float().mean()))
     res = chn.test_step(((x, m), y, info), 0)
     assert set(res) == {'ff', 'ip', 'cp'} and res['ff'].shape == x[0].shape
+
+
+def test_g13_cpn_aligner(golden, mt):
+    """The CPN aligner networks on the conv engine (A_Encoder, A_Regressor) and CPN.align against
+    the reference's outputs; its state-dict keys are the reference's."""
+    g = golden('g13_cpn_align')
+    model = mt.CPN()
+    sd = S.cpn_state_dict()
+    assert set(sd) == set(model.state_dict())
+    model.load_state_dict({'module.' + k: v for k, v in sd.items()} | {'Encoder.conv12.conv.0.weight': torch.zeros(1)})
+    model = model.to(DEV)
+    b, r, h, w = 2, 2, 64, 96
+    x_t = S.uniform('g13.xt', (b, 3, h, w)).to(DEV)
+    m_t = (S.uniform('g13.mt', (b, 1, h, w)) > 0.8).float().to(DEV)
+    x_r = S.uniform('g13.xr', (b, 3, r, h, w)).to(DEV)
+    m_r = (S.uniform('g13.mr', (b, 1, r, h, w)) > 0.8).float().to(DEV)
+    with torch.no_grad():
+        ft = model.A_Encoder(x_t, m_t)
+        assert_close(ft[:, ::16, ::4, ::4], g['feat_t'], what='A_Encoder')
+        fr = model.A_Encoder(x_r.transpose(1, 2).reshape(-1, 3, h, w), m_r.transpose(1, 2).reshape(-1, 1, h, w))
+        theta = model.A_Regressor(ft.unsqueeze(1).repeat(1, r, 1, 1, 1).reshape(-1, *ft.shape[1:]), fr)
+        np.testing.assert_allclose(theta.cpu().numpy(), g['theta'], rtol=1e-3, atol=2e-5)
+        xa, va, vm = model.align(x_t, m_t, x_r, m_r)
+    assert_close(xa, g['x_aligned'], tol=2e-3, what='x_aligned')
+    assert (va.cpu().numpy() != g['v_aligned']).mean() < 2e-3
+    assert (vm.cpu().numpy() != g['v_maps']).mean() < 2e-3
+    # and as the aligner of a CHN training step (--chn_aligner cpn upstream)
+    chn = mt.CHN(mt.VGGFeatures(device=DEV), None, model, **KW).to(DEV)
+    loss = chn.training_step(to_dev(S.synthetic_batch(1, 3, 64, 64, seed=3)), 0)
+    loss.backward()
+    assert np.isfinite(float(loss)) and all(p.grad is None for p in model.parameters())

@@ -208,3 +208,20 @@ def test_g12_inpainting_drivers(golden, chn_sd):
     with torch.no_grad():
         close(O.inpaint_ff(chn_sd, x[0], m[0]), g['ff'], rtol=2e-3)
         close(O.inpaint_cp(chn_sd, x[0], m[0], N=2), g['cp'], rtol=2e-3)
+
+
+def test_g13_cpn_aligner(golden):
+    """A_Encoder / A_Regressor / CPN.align against the reference (model_cpn.py:31-91, 121-174)."""
+    g = golden('g13_cpn_align')
+    sd = S.cpn_state_dict()
+    b, r, h, w = 2, 2, 64, 96
+    x_t = S.uniform('g13.xt', (b, 3, h, w))
+    m_t = (S.uniform('g13.mt', (b, 1, h, w)) > 0.8).float()
+    x_r = S.uniform('g13.xr', (b, 3, r, h, w))
+    m_r = (S.uniform('g13.mr', (b, 1, r, h, w)) > 0.8).float()
+    with torch.no_grad():
+        close(O.cpn_a_encoder(sd, x_t, m_t)[:, ::16, ::4, ::4], g['feat_t'], rtol=1e-3, atol=1e-4)
+        xa, va, vm, theta = O.cpn_align(sd, x_t, m_t, x_r, m_r)
+    close(theta, g['theta'], rtol=1e-3, atol=1e-5)
+    close(xa, g['x_aligned'], rtol=1e-3, atol=1e-4)
+    assert (va.numpy() != g['v_aligned']).mean() < 1e-3 and (vm.numpy() != g['v_maps']).mean() < 1e-3
