@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmt355.so')
-SOURCES = [('conv.hip', []), ('conv_halo.hip', []), ('stream.hip', ['-ffp-contract=off']), ('api.cpp', [])]
+SOURCES = [('conv.hip', []), ('conv_halo.hip', []), ('conv_halo_wgrad.hip', []), ('stream.hip', ['-ffp-contract=off']),
+           ('api.cpp', [])]
 
 
 def _stale(target, deps):
@@ -21,17 +22,23 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_common.h'),
                os.path.join(ROOT, 'include', 'mt355.h')]
-    objs = []
+    objs, cmds = [], []
     for src, extra in SOURCES:
         path = os.path.join(CSRC, src)
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
         objs.append(obj)
         if force or _stale(obj, [path] + headers):
-            cmd = [hipcc, '-x', 'hip', '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17',
-                   '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-c', path, '-o', obj] + extra
+            cmds.append([hipcc, '-x', 'hip', '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17',
+                         '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-c', path, '-o', obj] + extra)
+    if cmds:      # the translation units compile side by side (conv_halo.hip alone is ~1.5 minutes)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(5, len(cmds))) as ex:
+            list(ex.map(run, cmds))
     if force or _stale(LIB, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:

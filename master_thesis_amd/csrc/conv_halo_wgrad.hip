@@ -1,0 +1,264 @@
+// Weight gradient of the stride-1 / stride-2 3x3 and 5x5 layers on LDS halo tiles (its own
+// translation unit: the template instantiations compile beside those of conv_halo.hip).
+#include <cstdlib>
+#include "conv_common.h"
+
+// ------------------------------------------------------------ wgrad (halo) --
+// Weight gradient of the same stride-1 layers:
+//   dW[a][kh][kw][b] = sum_pixels D[pix][a] * G[pix + (kh,kw) - pad][b]
+// K = pixels.  A block owns a 64 x 64 (a, b) channel tile and KHB kernel rows
+// (all taps of a 3x3, one row of a 5x5) and walks over 4 x 16 pixel tiles: per
+// tile the D pixels and the G halo patch are loaded ONCE, split once, and
+// stored pixel-major exactly as they sit in HBM; the MFMA operands (which need
+// the pixel axis along k) come out of LDS through ds_read_b64_tr_b16, so a tap
+// is again only a row offset.  One k-step = one 16-pixel tile row.
+namespace {
+
+typedef __bf16 __attribute__((address_space(3))) lds_bf16;
+typedef bf16x4 __attribute__((address_space(3))) lds_bf16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int off, int ld) {
+  // two transposed 4(k) x 16(col) block reads -> this lane's 8 consecutive k
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(base + off + 4 * ld));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// ST = 2: the gathered tensor is sampled with stride 2 (a stride-2 Conv2d, or a stride-2
+// ConvTranspose2d with the roles of input and output gradient swapped): the patch is
+// (TR-1)*2+KHB x (TW-1)*2+KS pixels and the k rows of a G fragment are every second pixel.
+template <int KS, int KHB, int NS, int FMT, int OCC, int ST = 1, int TRP = 4>
+__global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split,
+                                                            int ntiles, int with_bias, int kh_base) {
+  constexpr int TR = TRP, TW = 16, PX = TR * TW;         // pixel tile: TR (4 or 8) rows x 16
+  constexpr int CH = 64, LD = CH + 8;                    // channel tile and LDS row (bf16)
+  constexpr int GH = (TR - 1) * ST + KHB, GW = (TW - 1) * ST + KS, GP = GH * GW;
+  constexpr int ND4 = PX * (CH / 4), RD = ND4 / 256;     // float4 loads per thread (D)
+  constexpr int NG4 = GP * (CH / 4), RG = (NG4 + 255) / 256;
+  constexpr int NT = KHB * KS;
+  __shared__ __attribute__((aligned(16))) __bf16 sD[NS][PX * LD];
+  __shared__ __attribute__((aligned(16))) __bf16 sG[NS][GP * LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bid = blockIdx.x;
+  const int bt = bid % p.btiles; bid /= p.btiles;
+  const int at = bid % p.atiles; bid /= p.atiles;
+  const int kh0 = kh_base + bid * KHB;     // first kernel row of this block
+  const int a0 = at * CH, b0 = bt * CH;
+  const int split = blockIdx.y;
+  const int t_beg = split * tiles_per_split, t_end = min(ntiles, t_beg + tiles_per_split);
+  const int HL = p.Hg << p.ups, WL = p.Wg << p.ups;
+  const float scD = FMT ? pow2_scale(*p.damax) : 1.f, scG = FMT ? pow2_scale(*p.gamax) : 1.f;
+  const float inv = 1.f / (scD * scG), inv_d = 1.f / scD;
+
+  // staging coordinates relative to the tile origin
+  int d_ry[RD], d_rx[RD], d_c[RD];
+#pragma unroll
+  for (int i = 0; i < RD; ++i) {
+    const int idx = tid + 256 * i, px = idx / (CH / 4);
+    d_c[i] = (idx % (CH / 4)) * 4; d_ry[i] = px >> 4; d_rx[i] = px & 15;
+  }
+  int g_y[RG], g_x[RG], g_c[RG];
+#pragma unroll
+  for (int i = 0; i < RG; ++i) {
+    const int idx = tid + 256 * i, gp = idx / (CH / 4);
+    g_c[i] = (idx % (CH / 4)) * 4; g_y[i] = gp / GW; g_x[i] = gp - g_y[i] * GW;
+  }
+
+  f32x4 rd[RD], rg[RG];
+  auto load_tile = [&](int t) {
+    const int tx = t % tiles_x, r = t / tiles_x, ty = r % tiles_y, n = r / tiles_y;
+    const int ty0 = ty * TR, tx0 = tx * TW;
+    const float* dp = p.d + (long)(n / p.dni) * p.dsg + (long)(n % p.dni) * p.dsn;
+    const float* gp = p.g + (long)(n / p.gni) * p.gsg + (long)(n % p.gni) * p.gsn;
+#pragma unroll
+    for (int i = 0; i < RD; ++i) {
+      const int y = ty0 + d_ry[i], x = tx0 + d_rx[i];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (y < p.Hd && x < p.Wd && a0 + d_c[i] < p.Cd)
+        v = *reinterpret_cast<const f32x4*>(dp + (long)y * p.dsh + (long)x * p.dsw + a0 + d_c[i]);
+      rd[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+      const int ly = ty0 * ST + g_y[i] + kh0 - p.pad, lx = tx0 * ST + g_x[i] - p.pad;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (tid + 256 * i < NG4 && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL && b0 + g_c[i] < p.Cg)
+        v = *reinterpret_cast<const f32x4*>(gp + (long)(ly >> p.ups) * p.gsh + (long)(lx >> p.ups) * p.gsw + b0 + g_c[i]);
+      rg[i] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < RD; ++i) {
+      bf16x4 parts[NS];
+      split4f<NS, FMT>(rd[i], scD, parts);
+      const int px = (tid + 256 * i) / (CH / 4);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sD[s][px * LD + d_c[i]]) = parts[s];
+    }
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+      if (tid + 256 * i < NG4) {
+        bf16x4 parts[NS];
+        split4f<NS, FMT>(rg[i], scG, parts);
+        const int gp = (tid + 256 * i) / (CH / 4);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sG[s][gp * LD + g_c[i]]) = parts[s];
+      }
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // bias gradient = sum_pixels D[pix][a]: one more MFMA chain against an
+  // all-ones operand, only in the blocks that own b-tile 0 / kernel row 0
+  const bool do_bias = with_bias && bt == 0 && kh0 == 0;
+  f32x16 acc_bias;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_bias[r] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = FMT ? __builtin_bit_cast(__bf16, (_Float16)1.0f) : (__bf16)1.0f;
+
+  // transposed-read lane coordinates: 16-lane group g = lane >> 4 covers columns
+  // 16*(g&1).., k rows 8*(g>>1) + q (+4); lane 4q+p supplies row q, columns 4p..
+  const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, g1 = (lane >> 4) & 1, lh = lane >> 5;
+  const int a_off = (8 * lh + q) * LD + wm * 32 + 16 * g1 + 4 * pp;
+  const int b_off = (8 * lh + q) * ST * LD + wn * 32 + 16 * g1 + 4 * pp;
+
+  if (t_beg < t_end) load_tile(t_beg);
+  for (int t = t_beg; t < t_end; ++t) {
+    __syncthreads();                          // previous tile's MFMA reads are done
+    store_tile();
+    __syncthreads();
+    if (t + 1 < t_end) load_tile(t + 1);      // in flight during the MFMA phase
+#pragma unroll
+    for (int ks = 0; ks < TR; ++ks) {
+      bf16x8 fa[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) fa[s] = tr_frag(sD[s], a_off + ks * 16 * LD, LD);
+      if (do_bias) {
+#pragma unroll
+        for (int s = NS - 1; s >= 0; --s) {
+          if constexpr (FMT == 0) acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], ones, acc_bias, 0, 0, 0);
+          else acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[s]), __builtin_bit_cast(half8, ones), acc_bias, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int kh = 0; kh < KHB; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+          bf16x8 fb[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) fb[s] = tr_frag(sG[s], b_off + ((ks * ST + kh) * GW + kw) * LD, ST * LD);
+          mfma_splitf<NS, FMT>(fa, fb, acc[kh * KS + kw]);
+        }
+    }
+  }
+
+  const int T = p.KH * p.KW, li = lane & 31;
+  const int TS = T + (with_bias ? 1 : 0);        // the bias sums travel as one more "tap" (column 0)
+  float* slab = p.slabs + (long)split * p.Cd * TS * p.Cg;
+  if (do_bias && wn == 0 && li == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ai < p.Cd) slab[((long)ai * TS + T) * p.Cg] = acc_bias[r] * inv_d;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tap = (kh0 + t / KS) * KS + (t % KS);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int bi = b0 + wn * 32 + li;
+      if (ai < p.Cd && bi < p.Cg) slab[((long)ai * TS + tap) * p.Cg + bi] = acc[t][r] * inv;
+    }
+  }
+}
+
+}  // namespace
+
+namespace {
+// MT355_WGRAD5_ROWS=1 restores one kernel row per block for the 5x5 weight gradient (A/B switch)
+// MT355_WGRAD_S2_HALO=0: stride-2 weight gradients stay on the generic kernel (A/B switch)
+bool wgrad_s2_halo() {
+  static const bool on = [] { const char* e = getenv("MT355_WGRAD_S2_HALO"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// MT355_WGRAD3_TALL=0: 4-row pixel tiles for the 3x3 weight gradient (A/B switch)
+bool wgrad3_tall() {
+  static const bool on = [] { const char* e = getenv("MT355_WGRAD3_TALL"); return !(e && e[0] == '0'); }();
+  return on;
+}
+bool wgrad5_rows32() {
+  static const bool on = [] { const char* e = getenv("MT355_WGRAD5_ROWS"); return !(e && e[0] == '1'); }();
+  return on;
+}
+}  // namespace
+
+// Called by mt_wgrad_run: returns 1 if the launch was taken by the halo kernel.
+// `splits` blocks along y each own a contiguous range of pixel tiles.
+int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
+  const int prec = d->precision;
+  if (prec != MT_PREC_BF16X3 && prec != MT_PREC_BF16X6 && prec != MT_PREC_F16X3) return 0;
+  if ((d->stride != 1 && d->stride != 2) || d->KH != d->KW || (d->KH != 3 && d->KH != 5) || d->pad != d->KH / 2) return 0;
+  if (d->stride == 2 && (d->ups != 0 || prec == MT_PREC_BF16X6 || !wgrad_s2_halo())) return 0;
+  if (prec == MT_PREC_F16X3 && (!d->d_amax || !d->g_amax)) return 0;
+  WgK k;
+  k.d = d->d.p; k.dsn = d->d.sn; k.dsh = d->d.sh; k.dsw = d->d.sw; k.Hd = d->d.H; k.Wd = d->d.W; k.Cd = d->d.C;
+  k.g = d->g.p; k.gsn = d->g.sn; k.gsh = d->g.sh; k.gsw = d->g.sw; k.Hg = d->g.H; k.Wg = d->g.W; k.Cg = d->g.C;
+  k.dni = d->d.n_in; k.dsg = d->d.sg; k.gni = d->g.n_in; k.gsg = d->g.sg;
+  k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.ups = d->ups;
+  k.M = d->d.N * d->d.H * d->d.W; k.per_split = 0;
+  k.atiles = (k.Cd + 63) / 64; k.btiles = (k.Cg + 63) / 64;
+  k.slabs = d->slabs;
+  k.damax = d->d_amax; k.gamax = d->g_amax;
+  // 3x3 stride 1 (two-term splits): 8-row pixel tiles (measured: +6 %; the 5x5 gradient loses 3 % with them) (twice the MFMAs per staged tile and barrier)
+  const bool tall = d->stride == 1 && d->KH == 3 && prec != MT_PREC_BF16X6 && wgrad3_tall();
+  const int trows = tall ? 8 : 4;
+  const int tiles_y = (k.Hd + trows - 1) / trows, tiles_x = (k.Wd + 15) / 16;
+  const int ntiles = d->d.N * tiles_y * tiles_x;
+  const int tps = (ntiles + d->splits - 1) / d->splits;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define MT_WGH(KS, KHB, NS, FMT, OCC, GRID, KH_BASE) \
+  hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, NS, FMT, OCC>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
+#define MT_WGH2(KS, KHB, FMT, GRID, KH_BASE) \
+  hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
+  if (d->stride == 2) {      // stride-2 gather: all 9 taps, or kernel rows {0,1,2} | {3,4}
+    dim3 grid(k.atiles * k.btiles, d->splits);
+    const bool f16 = prec == MT_PREC_F16X3;
+    if (d->KH == 3) { if (f16) MT_WGH2(3, 3, 1, grid, 0); else MT_WGH2(3, 3, 0, grid, 0); }
+    else if (f16) { MT_WGH2(5, 3, 1, grid, 0); MT_WGH2(5, 2, 1, grid, 3); }
+    else { MT_WGH2(5, 3, 0, grid, 0); MT_WGH2(5, 2, 0, grid, 3); }
+  } else if (d->KH == 3) {   // all nine taps per block, one block per CU (the 9 accumulator tiles need the registers)
+    dim3 grid(k.atiles * k.btiles, d->splits);
+    if (prec == MT_PREC_BF16X6) MT_WGH(3, 3, 3, 0, 1, grid, 0);
+    else if (tall && prec == MT_PREC_BF16X3)
+      hipLaunchKernelGGL((wgrad_halo_kernel<3, 3, 2, 0, 1, 1, 8>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0);
+    else if (tall)
+      hipLaunchKernelGGL((wgrad_halo_kernel<3, 3, 2, 1, 1, 1, 8>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0);
+    else if (prec == MT_PREC_BF16X3) MT_WGH(3, 3, 2, 0, 1, grid, 0);
+    else MT_WGH(3, 3, 2, 1, 1, grid, 0);
+  } else if (prec == MT_PREC_BF16X6 || !wgrad5_rows32()) {   // one kernel row (5 taps) per block
+    dim3 grid(k.atiles * k.btiles * 5, d->splits);
+    if (prec == MT_PREC_BF16X6) MT_WGH(5, 1, 3, 0, 2, grid, 0);
+    else if (prec == MT_PREC_BF16X3) MT_WGH(5, 1, 2, 0, 2, grid, 0);
+    else MT_WGH(5, 1, 2, 1, 2, grid, 0);
+  } else {            // kernel rows {0,1,2} and {3,4}: 15 / 10 taps per block, one block per CU; each
+                      // pixel tile is staged twice instead of five times
+    dim3 grid(k.atiles * k.btiles, d->splits);
+    if (prec == MT_PREC_BF16X3) { MT_WGH(5, 3, 2, 0, 1, grid, 0); MT_WGH(5, 2, 2, 0, 1, grid, 3); }
+    else { MT_WGH(5, 3, 2, 1, 1, grid, 0); MT_WGH(5, 2, 2, 1, 1, grid, 3); }
+  }
+#undef MT_WGH
+#undef MT_WGH2
+  return 1;
+}
+
