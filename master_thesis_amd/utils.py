@@ -108,3 +108,80 @@ class LossesUtils:
         if reduction == 'sum':   # mask of ones: sum / (numel + 1e-9)
             return weight * acc / (float(n * 2 * c * h * w) + 1e-9)
         return weight * acc / float(n * 2 * c * h * w)
+
+
+class MovementsUtils:
+    """utils.py:227-401: synthetic camera movement for a still image -- the data either side of the
+    training step (dataset.py:596-601), kept on the device: the 3x3 matrix algebra is host-side as
+    upstream (a few dozen flops), the sampling grids and the bilinear warp of all frames run on the GPU
+    (one fused warp launch for the whole sequence)."""
+
+    def __init__(self, max_displacement, max_scaling, max_rotation):
+        self.max_displacement, self.max_scaling, self.max_rotation = max_displacement, max_scaling, max_rotation
+
+    def random_affine(self, rng=None):
+        """utils.py:243-260 (same draws, same order; the matrix is skimage's
+        AffineTransform(translation, scale, rotation).params written out)."""
+        import numpy as np
+        rng = rng or np.random
+        tx, ty = rng.randint(low=-self.max_displacement, high=self.max_displacement, size=2) \
+            if self.max_displacement > 0 else (0, 0)
+        sx, sy = rng.uniform(low=1 - self.max_scaling, high=1 + self.max_scaling, size=2)
+        rot = rng.uniform(low=-self.max_rotation, high=self.max_rotation)
+        return torch.tensor([[sx * np.cos(rot), -sy * np.sin(rot), tx], [sx * np.sin(rot), sy * np.cos(rot), ty],
+                             [0.0, 0.0, 1.0]], dtype=torch.float32)
+
+    @staticmethod
+    def identity_affine():
+        return torch.eye(3, dtype=torch.float32)
+
+    @staticmethod
+    def affine_inverse(affine):
+        return torch.inverse(affine)
+
+    @staticmethod
+    def stack_transformations(affine_matrices, t):
+        """utils.py:347-377."""
+        out = torch.zeros(affine_matrices.size(), dtype=torch.float32)
+        out[t] = affine_matrices[t]
+        for i in reversed(range(t)):
+            out[i] = torch.matmul(torch.inverse(affine_matrices[i]), out[i + 1])
+        for i in range(t + 1, len(affine_matrices)):
+            out[i] = torch.matmul(affine_matrices[i], out[i - 1])
+        return out
+
+    @staticmethod
+    def affine2theta(param, h, w):
+        """utils.py:379-401."""
+        return torch.tensor([[param[0, 0], param[0, 1] * h / w, param[0, 2] * 2 / w + param[0, 0] + param[0, 1] - 1],
+                             [param[1, 0] * w / h, param[1, 1], param[1, 2] * 2 / h + param[1, 0] + param[1, 1] - 1]],
+                            dtype=torch.float32)
+
+    @staticmethod
+    def _affine_grid(theta, h, w):
+        """F.affine_grid(theta, [n, c, h, w], align_corners=True) on theta's device: base
+        coordinates linspace(-1, 1)."""
+        n = theta.shape[0]
+        xs = torch.linspace(-1, 1, w, device=theta.device)
+        ys = torch.linspace(-1, 1, h, device=theta.device)
+        base = torch.stack([xs.view(1, w).expand(h, w), ys.view(h, 1).expand(h, w),
+                            torch.ones((h, w), device=theta.device)], dim=2)
+        return torch.matmul(base.view(1, h * w, 3), theta.transpose(1, 2)).view(n, h, w, 2)
+
+    def simulate_movement(self, x, n, affine_matrices=None):
+        """utils.py:262-318.  x (C,H,W) on the GPU -> (y (C,n,H,W), flow_inv (n,H,W,2), affine_matrices)."""
+        c, h, w = x.size()
+        if affine_matrices is None:
+            affine_matrices = [self.random_affine() for _ in range(n - 1)]
+            affine_matrices = affine_matrices[: n // 2] + [MovementsUtils.identity_affine()] + affine_matrices[n // 2:]
+        inv = [MovementsUtils.affine_inverse(a) for a in affine_matrices]
+        st = MovementsUtils.stack_transformations(torch.stack(list(affine_matrices)), t=n // 2)
+        st_inv = MovementsUtils.stack_transformations(torch.stack(inv), t=n // 2)
+        theta = torch.stack([MovementsUtils.affine2theta(a, h, w) for a in st]).to(x.device)
+        theta_inv = torch.stack([MovementsUtils.affine2theta(a, h, w) for a in st_inv]).to(x.device)
+        flow = MovementsUtils._affine_grid(theta, h, w)
+        flow_inv = MovementsUtils._affine_grid(theta_inv, h, w)
+        # every frame samples the same still image: (1,C,n,H,W) view, one warp launch
+        xs = x.unsqueeze(0).unsqueeze(2).expand(1, c, n, h, w).contiguous()
+        y, _ = ops.align_set(xs, None, flow.unsqueeze(0), align_corners=True)
+        return y[0], flow_inv, affine_matrices

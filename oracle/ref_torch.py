@@ -609,3 +609,37 @@ def cpn_align(sd, x_t, m_t, x_r, m_r):
     fr = cpn_a_encoder(sd, fold_frames(x_r), fold_frames(m_r))
     theta = cpn_a_regressor(sd, ft.unsqueeze(1).repeat(1, r, 1, 1, 1).reshape(-1, *ft.shape[1:]), fr)
     return cpn_warp(x_r, m_r, m_t, theta) + (theta,)
+
+
+# --------------------------------------------------------------------------
+# synthetic camera movement, utils.py:262-401
+# --------------------------------------------------------------------------
+def stack_transformations(mats, t):
+    """MovementsUtils.stack_transformations, utils.py:347-377: transformations relative to frame t."""
+    out = torch.zeros_like(mats)
+    out[t] = mats[t]
+    for i in reversed(range(t)):
+        out[i] = torch.inverse(mats[i]) @ out[i + 1]
+    for i in range(t + 1, len(mats)):
+        out[i] = mats[i] @ out[i - 1]
+    return out
+
+
+def affine2theta(a, h, w):
+    """MovementsUtils.affine2theta, utils.py:379-401 (pixel matrix -> affine_grid theta)."""
+    return torch.tensor([[a[0, 0], a[0, 1] * h / w, a[0, 2] * 2 / w + a[0, 0] + a[0, 1] - 1],
+                         [a[1, 0] * w / h, a[1, 1], a[1, 2] * 2 / h + a[1, 0] + a[1, 1] - 1]], dtype=torch.float32)
+
+
+def simulate_movement(x, mats):
+    """MovementsUtils.simulate_movement with explicit matrices, utils.py:262-318.
+    x (C,H,W), mats (n,3,3) -> y (C,n,H,W), flow_inv (n,H,W,2)."""
+    n, (c, h, w) = len(mats), x.shape
+    st = stack_transformations(mats, n // 2)
+    st_inv = stack_transformations(torch.stack([torch.inverse(a) for a in mats]), n // 2)
+    theta = torch.stack([affine2theta(a, h, w) for a in st])
+    theta_inv = torch.stack([affine2theta(a, h, w) for a in st_inv])
+    flow = F.affine_grid(theta, [n, c, h, w], align_corners=True)
+    flow_inv = F.affine_grid(theta_inv, [n, c, h, w], align_corners=True)
+    y = F.grid_sample(x.unsqueeze(0).repeat(n, 1, 1, 1), flow, align_corners=True)
+    return y.permute(1, 0, 2, 3), flow_inv

@@ -309,8 +309,43 @@ def g13_cpn_align():
     save('g13_cpn_align', feat_t=ft[:, ::16, ::4, ::4], theta=theta, x_aligned=xa, v_aligned=va, v_maps=vm)
 
 
+def movement_matrices(n, seed_name):
+    """n explicit 3x3 affine matrices (pixels; translation, anisotropic scale, rotation), identity in the
+    middle: the form MovementsUtils.random_affine produces (utils.py:243-260)."""
+    mats = []
+    u = S.uniform(seed_name, (n, 5), -1, 1)
+    for i in range(n):
+        tx, ty, rot = float(u[i, 0]) * 12, float(u[i, 1]) * 12, float(u[i, 4]) * 0.1
+        sx, sy = 1 + float(u[i, 2]) * 0.05, 1 + float(u[i, 3]) * 0.05
+        mats.append(torch.tensor([[sx * np.cos(rot), -sy * np.sin(rot), tx],
+                                  [sx * np.sin(rot), sy * np.cos(rot), ty], [0.0, 0.0, 1.0]], dtype=torch.float32))
+    mats[n // 2] = torch.eye(3)
+    return mats
+
+
+def g14_movement():
+    """MovementsUtils.simulate_movement with explicit matrices (utils.py:262-318).  The method itself
+    cannot run in this image (its affine_inverse, utils.py:345, hands a Tensor to np.linalg.inv and then to
+    torch.from_numpy: a numpy-2 / torch-2.10 skew, an ordinary TypeError), so the golden chains the
+    reference's own helpers stack_transformations / affine2theta (utils.py:347-401) with the two torch calls
+    the method makes (utils.py:308-318); the per-matrix inverses come from torch.inverse."""
+    import torch.nn.functional as F
+    M = mt.MovementsUtils
+    x = S.uniform('g14.x', (3, 48, 64))
+    n, (c, h, w) = 5, x.shape
+    mats = torch.stack(movement_matrices(n, 'g14.m'))
+    stacked = M.stack_transformations(mats, t=n // 2)
+    stacked_inv = M.stack_transformations(torch.stack([torch.inverse(a) for a in mats]), t=n // 2)
+    theta = torch.stack([M.affine2theta(a, h, w) for a in stacked])
+    theta_inv = torch.stack([M.affine2theta(a, h, w) for a in stacked_inv])
+    flow = F.affine_grid(theta, [n, c, h, w], align_corners=True)
+    flow_inv = F.affine_grid(theta_inv, [n, c, h, w], align_corners=True)
+    y = F.grid_sample(x.unsqueeze(0).repeat(n, 1, 1, 1), flow, align_corners=True).permute(1, 0, 2, 3)
+    save('g14_movement', y=y, flow_inv=flow_inv, stacked=stacked, theta=theta)
+
+
 ALL = [g1_corr, g2_warp, g3_resize, g4_modules, g5_dfpn_fwd, g6_dfpn_loss,
-       g7_rrdbnet, g8_chn_loss, g9_grads, g10_vgg, g11_cpn_warp, g12_inpaint, g13_cpn_align]
+       g7_rrdbnet, g8_chn_loss, g9_grads, g10_vgg, g11_cpn_warp, g12_inpaint, g13_cpn_align, g14_movement]
 
 if __name__ == '__main__':
     torch.set_num_threads(os.cpu_count())

@@ -343,3 +343,19 @@ def test_adam_matches_torch(mt):
         opt_r.step()
     for a, b in zip(mine, ref):
         assert_close(a, b, 1e-5, 'adam')
+
+
+def test_g14_simulate_movement(mt, golden):
+    """MovementsUtils.simulate_movement on the device (one fused warp launch for the sequence) against
+    the reference's helpers + torch calls (golden g14)."""
+    from test_oracle_golden import _movement_matrices
+    g = golden('g14_movement')
+    x = S.uniform('g14.x', (3, 48, 64)).to(dev())
+    mats = _movement_matrices(5, 'g14.m')
+    sim = mt.MovementsUtils(50, 0.1, 0.2)
+    np.testing.assert_allclose(sim.stack_transformations(mats, 2).numpy(), g['stacked'], rtol=1e-5, atol=1e-6)
+    y, flow_inv, used = sim.simulate_movement(x, 5, [m for m in mats])
+    assert_close(y, torch.from_numpy(g['y']), what='y')
+    assert_close(flow_inv, torch.from_numpy(g['flow_inv']), tol=1e-5, what='flow_inv')
+    y2, _, mats2 = sim.simulate_movement(x, 5)                   # random movement: identity in the middle
+    assert len(mats2) == 5 and torch.equal(mats2[2], torch.eye(3)) and float((y2[:, 2] - x).abs().max()) < 1e-5

@@ -225,3 +225,26 @@ def test_g13_cpn_aligner(golden):
     close(theta, g['theta'], rtol=1e-3, atol=1e-5)
     close(xa, g['x_aligned'], rtol=1e-3, atol=1e-4)
     assert (va.numpy() != g['v_aligned']).mean() < 1e-3 and (vm.numpy() != g['v_maps']).mean() < 1e-3
+
+
+def _movement_matrices(n, seed_name):
+    mats = []
+    u = S.uniform(seed_name, (n, 5), -1, 1)
+    for i in range(n):
+        tx, ty, rot = float(u[i, 0]) * 12, float(u[i, 1]) * 12, float(u[i, 4]) * 0.1
+        sx, sy = 1 + float(u[i, 2]) * 0.05, 1 + float(u[i, 3]) * 0.05
+        mats.append(torch.tensor([[sx * np.cos(rot), -sy * np.sin(rot), tx],
+                                  [sx * np.sin(rot), sy * np.cos(rot), ty], [0.0, 0.0, 1.0]], dtype=torch.float32))
+    mats[n // 2] = torch.eye(3)
+    return torch.stack(mats)
+
+
+def test_g14_simulate_movement(golden):
+    """Synthetic camera movement (utils.py:262-401) against the reference's helpers."""
+    g = golden('g14_movement')
+    x = S.uniform('g14.x', (3, 48, 64))
+    mats = _movement_matrices(5, 'g14.m')
+    close(O.stack_transformations(mats, 2), g['stacked'], rtol=1e-5)
+    y, flow_inv = O.simulate_movement(x, mats)
+    close(y, g['y'], rtol=1e-4, atol=1e-5)
+    close(flow_inv, g['flow_inv'], rtol=1e-4, atol=1e-5)
