@@ -146,6 +146,9 @@ typedef struct {
                          KH*KW + 1 taps, tap KH*KW / column 0 = those sums */
   const float* d_amax; /* MT_PREC_F16X3: device scalars >= max|D|, max|G| */
   const float* g_amax;
+  uint32_t skip_tiles; /* halo-tile path: bit (at * btiles + bt) set = the 64 x 64 channel tile (D channels
+                          64*at.., G channels 64*bt..) is not wanted and its slab entries stay undefined (a
+                          launch shared by several layers forms a block-triangular product); 0 = all */
 } mt_wgrad;
 
 int mt_wgrad_run(const mt_wgrad* d, void* stream);

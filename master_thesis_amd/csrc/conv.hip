@@ -866,6 +866,7 @@ extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
   MT_REQUIRE((int64_t)k.per_split * d->splits >= k.M, "mt_wgrad: split arithmetic");
   k.slabs = d->slabs;
   k.damax = d->d_amax; k.gamax = d->g_amax;
+  k.skip = 0;
   int cfg;
   wgrad_cfg(d, &k.atiles, &k.btiles, &cfg);
   dim3 grid(k.atiles * k.btiles * d->KH * d->KW, d->splits);

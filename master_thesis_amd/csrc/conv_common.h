@@ -186,6 +186,7 @@ struct WgK {
   int atiles, btiles;
   float* slabs;
   const float* damax; const float* gamax;   // F16X3: device scalars max|D|, max|G|
+  unsigned skip;                            // halo path: bit (at*btiles+bt) = tile not wanted
 };
 
 inline int fill_convk(const mt_conv* d, ConvK* k) {

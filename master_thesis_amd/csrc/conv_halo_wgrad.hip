@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
   const int bt = bid % p.btiles; bid /= p.btiles;
   const int at = bid % p.atiles; bid /= p.atiles;
   const int kh0 = kh_base + bid * KHB;     // first kernel row of this block
+  if (at * p.btiles + bt < 32 && ((p.skip >> (at * p.btiles + bt)) & 1u)) return;   // tile nobody reads
   const int a0 = at * CH, b0 = bt * CH;
   const int split = blockIdx.y;
   const int t_beg = split * tiles_per_split, t_end = min(ntiles, t_beg + tiles_per_split);
@@ -220,6 +221,7 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   k.atiles = (k.Cd + 63) / 64; k.btiles = (k.Cg + 63) / 64;
   k.slabs = d->slabs;
   k.damax = d->d_amax; k.gamax = d->g_amax;
+  k.skip = d->skip_tiles;
   // 3x3 stride 1 (two-term splits): 8-row pixel tiles (measured: +6 %; the 5x5 gradient loses 3 % with them) (twice the MFMAs per staged tile and barrier)
   const bool tall = d->stride == 1 && d->KH == 3 && prec != MT_PREC_BF16X6 && wgrad3_tall();
   const int trows = tall ? 8 : 4;

@@ -634,6 +634,15 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     # on the halo path the bias gradient rides along as one more slab "tap"
     fused_bias = halo and need_bias and spec.kind == 'c'
     d.with_bias = 1 if fused_bias else 0
+    if sub_blocks is not None and halo:
+        # block-triangular product: 64 x 64 tiles (a-tile, b-tile) that no sub-block reads are skipped
+        nbt = (bp + 63) // 64
+        need = set()
+        for sb in sub_blocks:
+            for at_ in range(sb[0] // 64, (sb[0] + sb[1] - 1) // 64 + 1):
+                for bt_ in range(0, (sb[2] - 1) // 64 + 1):
+                    need.add(at_ * nbt + bt_)
+        d.skip_tiles = sum(1 << i for i in range(min(32, ((ap + 63) // 64) * nbt)) if i not in need)
     ts = t + (1 if fused_bias else 0)
     slabs = torch.empty((d.splits * ap * ts * bp,), device=w.device, dtype=torch.float32)
     d.slabs = slabs.data_ptr()
