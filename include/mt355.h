@@ -289,6 +289,20 @@ int mt_axpby(const mt_view* x, float a, const mt_view* z, float b,
 int mt_dact(const mt_view* x, const mt_view* s, int32_t act, const mt_view* y,
             void* stream);
 
+/* Output stage of CHN.forward (model_chn.py:81-85) straight from the network's NHWC output:
+ *   y_hat[b,c,f,y,x]  = clamp(o[(b*F+f),y,x,c] * std[c] + mean[c], 0, 1)
+ *   y_comp[b,c,f,y,x] = v[b,0,y,x] * x_t[b,c,y,x] + (1 - v[b,0,y,x]) * y_hat[b,c,f,y,x]
+ * o: NHWC view (B*F, H, W, >= 3); x_t (B,3,H,W), v (B,1,H,W), y_hat / y_comp (B,3,F,H,W) contiguous. */
+int mt_compose_clamp_fwd(const mt_view* o, const float* x_t, const float* v,
+                         const float* mean3, const float* std3, int32_t B, int32_t F,
+                         float* y_hat, float* y_comp, void* stream);
+/* and its gradient wrt o (channels >= 3 of d_o are zeroed):
+ *   d_o = (d_y_hat + (1 - v) * d_y_comp) * std[c] * [0 <= o*std+mean <= 1]
+ * d_y_hat / d_y_comp: (B,3,F,H,W) contiguous, either may be NULL. */
+int mt_compose_clamp_bwd(const mt_view* o, const float* v, const float* mean3,
+                         const float* std3, int32_t B, int32_t F, const float* d_y_hat,
+                         const float* d_y_comp, const mt_view* d_o, void* stream);
+
 /* Masked cosine-similarity correlation volume
  * (CorrelationVGG.correlation_masked_4d, model_dfpn.py:534-565).
  * ft: NHWC4 (B, h, w, C) target features; fr: NHWC4 (B*R, h, w, C), image

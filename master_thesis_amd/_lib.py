@@ -96,6 +96,8 @@ SIGNATURES = {
     'mt_nchw_to_nhwc4': [_vp, i64, i64, i64, i64, i32, i32, i32, i32, _vp, _vp, _P(View), i32, _vp],
     'mt_nhwc4_to_nchw': [_P(View), i32, _vp, i64, i64, i64, i64, i32, _vp, _vp, i32, _vp],
     'mt_pack_pairs': [_P(PackSrc), i32, i32, i32, _P(View), _vp],
+    'mt_compose_clamp_fwd': [_P(View), _vp, _vp, _vp, _vp, i32, i32, _vp, _vp, _vp],
+    'mt_compose_clamp_bwd': [_P(View), _vp, _vp, _vp, i32, i32, _vp, _vp, _P(View), _vp],
     'mt_maxpool2x2': [_P(View), _P(View), _vp],
     'mt_sumpool': [_P(View), _P(View), i32, _vp],
     'mt_axpby': [_P(View), f32, _P(View), f32, _P(View), _vp, _vp],

@@ -60,6 +60,55 @@ __global__ void nhwc4_to_nchw_kernel(const float* src, long sn, long sh, long sw
   }
 }
 
+// CHN output stage (model_chn.py:81-85): de-normalise + clamp + compose, NHWC -> (B,3,F,H,W)
+__global__ void compose_clamp_fwd_kernel(const float* o, long osn, long osh, long osw, const float* xt, const float* v,
+                                         const float* mean, const float* stdv, int B, int F, int H, int W,
+                                         float* yhat, float* ycomp) {
+  const long total = (long)B * F * H * W;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(e % W);
+    long r = e / W;
+    const int y = (int)(r % H); r /= H;
+    const int f = (int)(r % F);
+    const int b = (int)(r / F);
+    const float* op = o + ((long)b * F + f) * osn + (long)y * osh + (long)x * osw;
+    const long hw = (long)H * W, pix = (long)y * W + x;
+    const float vis = v[b * hw + pix];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float yh = fminf(fmaxf(op[c] * stdv[c] + mean[c], 0.f), 1.f);
+      const long oi = (((long)b * 3 + c) * F + f) * hw + pix;
+      yhat[oi] = yh;
+      ycomp[oi] = vis * xt[((long)b * 3 + c) * hw + pix] + (1.f - vis) * yh;
+    }
+  }
+}
+
+__global__ void compose_clamp_bwd_kernel(const float* o, long osn, long osh, long osw, const float* v, const float* mean,
+                                         const float* stdv, int B, int F, int H, int W, const float* dyh,
+                                         const float* dyc, float* d_o, long dsn, long dsh, long dsw, int Cd) {
+  const long total = (long)B * F * H * W;
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(e % W);
+    long r = e / W;
+    const int y = (int)(r % H); r /= H;
+    const int f = (int)(r % F);
+    const int b = (int)(r / F);
+    const float* op = o + ((long)b * F + f) * osn + (long)y * osh + (long)x * osw;
+    float* dp = d_o + ((long)b * F + f) * dsn + (long)y * dsh + (long)x * dsw;
+    const long hw = (long)H * W, pix = (long)y * W + x;
+    const float keep = 1.f - v[b * hw + pix];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float pre = op[c] * stdv[c] + mean[c];
+      const long oi = (((long)b * 3 + c) * F + f) * hw + pix;
+      float g = (dyh ? dyh[oi] : 0.f) + (dyc ? keep * dyc[oi] : 0.f);
+      dp[c] = (pre >= 0.f && pre <= 1.f) ? g * stdv[c] : 0.f;      // clamp passes the gradient on [0, 1] (ATen)
+    }
+    for (int c = 3; c < Cd; ++c) dp[c] = 0.f;
+  }
+}
+
 __global__ void maxpool2x2_kernel(const float* x, long xn, long xh, long xw, float* y, long yn, long yh, long yw, int N,
                                   int Ho, int Wo, int C4) {
   const long total = (long)N * Ho * Wo * C4;
@@ -614,6 +663,30 @@ extern "C" int mt_nhwc4_to_nchw(const mt_view* src, int32_t c_off, float* dst, i
                      (long)src->sn, (long)src->sh, (long)src->sw, src->N, src->H, src->W, c_off, dst, (long)d_n,
                      (long)d_c, (long)d_h, (long)d_w, C, scale, shift, accumulate);
   return mt_check_launch("mt_nhwc4_to_nchw");
+}
+
+extern "C" int mt_compose_clamp_fwd(const mt_view* o, const float* x_t, const float* v, const float* mean3,
+                                    const float* std3, int32_t B, int32_t F, float* y_hat, float* y_comp,
+                                    void* stream) {
+  MT_REQUIRE(mt_view_flat(o) && x_t && v && mean3 && std3 && y_hat && y_comp && B > 0 && F > 0 && o->N == B * F &&
+                 o->C >= 3, "mt_compose_clamp_fwd: bad arguments");
+  const long total = (long)B * F * o->H * o->W;
+  hipLaunchKernelGGL(compose_clamp_fwd_kernel, dim3(mt_grid_1d(total, 256)), dim3(256), 0, S_(stream), o->p, (long)o->sn,
+                     (long)o->sh, (long)o->sw, x_t, v, mean3, std3, B, F, o->H, o->W, y_hat, y_comp);
+  return mt_check_launch("mt_compose_clamp_fwd");
+}
+
+extern "C" int mt_compose_clamp_bwd(const mt_view* o, const float* v, const float* mean3, const float* std3, int32_t B,
+                                    int32_t F, const float* d_y_hat, const float* d_y_comp, const mt_view* d_o,
+                                    void* stream) {
+  MT_REQUIRE(mt_view_flat(o) && mt_view_flat(d_o) && v && mean3 && std3 && B > 0 && F > 0 && o->N == B * F &&
+                 o->C >= 3 && d_o->N == o->N && d_o->H == o->H && d_o->W == o->W && d_o->C >= 3,
+             "mt_compose_clamp_bwd: bad arguments");
+  const long total = (long)B * F * o->H * o->W;
+  hipLaunchKernelGGL(compose_clamp_bwd_kernel, dim3(mt_grid_1d(total, 256)), dim3(256), 0, S_(stream), o->p, (long)o->sn,
+                     (long)o->sh, (long)o->sw, v, mean3, std3, B, F, o->H, o->W, d_y_hat, d_y_comp, d_o->p,
+                     (long)d_o->sn, (long)d_o->sh, (long)d_o->sw, d_o->C);
+  return mt_check_launch("mt_compose_clamp_bwd");
 }
 
 extern "C" int mt_maxpool2x2(const mt_view* x, const mt_view* y, void* stream) {

@@ -338,12 +338,9 @@ class CHN(LightningModule):
         mean, std = self.mean.reshape(3), self.std.reshape(3)
         scale, shift = (1.0 / std).contiguous(), (-mean / std).contiguous()
         nn_input = ops.pack_chn_input(x_target, v_target, x_refs_aligned, v_refs_aligned, v_maps, scale, shift)
-        out4 = self.nn.forward4(nn_input)                                  # (b*f,h,w,4)
-        nn_output = E.FromNHWC4Fn.apply(out4, c).reshape(b, f, c, h, w).transpose(1, 2)
-        x_target = x_target.unsqueeze(2)
-        v_target = v_target.unsqueeze(2)
-        y_hat = torch.clamp(nn_output * self.std + self.mean, 0, 1)
-        y_hat_comp = v_target * x_target + (1 - v_target) * y_hat
+        out4 = self.nn.forward4(nn_input)                                  # (b*f,h,w,8)
+        # de-normalise, clamp, compose with the visible target pixels: one fused kernel each way
+        y_hat, y_hat_comp = ops.ComposeClampFn.apply(out4, x_target, v_target, mean.contiguous(), std.contiguous(), b, f)
         return y_hat, y_hat_comp
 
     def _step(self, batch):

@@ -174,6 +174,36 @@ def pack_chn_input(x_t, v_t, x_ra, v_ra, v_maps, scale, shift):
 
 
 # ----------------------------------------------------------- correlation ---
+class ComposeClampFn(torch.autograd.Function):
+    """Output stage of CHN.forward (model_chn.py:81-85) from the network's NHWC output:
+    (y_hat, y_hat_comp) = (clamp(o*std+mean, 0, 1), v*x_t + (1-v)*y_hat), both (B,3,F,H,W).
+    Differentiable wrt the network output only (x_t and v are data)."""
+
+    @staticmethod
+    def forward(ctx, out4, x_t, v_t, mean3, std3, b, f):
+        _chk(out4, x_t, v_t, mean3, std3)
+        x_t, v_t = x_t.contiguous(), v_t.contiguous()
+        h, w = out4.shape[1:3]
+        y_hat = torch.empty((b, 3, f, h, w), device=out4.device, dtype=torch.float32)
+        y_comp = torch.empty_like(y_hat)
+        L.call('mt_compose_clamp_fwd', C.byref(view_of(out4)), L.ptr(x_t), L.ptr(v_t), L.ptr(mean3), L.ptr(std3), b, f,
+               L.ptr(y_hat), L.ptr(y_comp), L.stream_ptr())
+        ctx.save_for_backward(out4, v_t, mean3, std3)
+        ctx.bf = (b, f)
+        return y_hat, y_comp
+
+    @staticmethod
+    def backward(ctx, d_hat, d_comp):
+        out4, v_t, mean3, std3 = ctx.saved_tensors
+        b, f = ctx.bf
+        d_hat = d_hat.contiguous() if d_hat is not None else None
+        d_comp = d_comp.contiguous() if d_comp is not None else None
+        d_o = torch.empty_like(out4)
+        L.call('mt_compose_clamp_bwd', C.byref(view_of(out4)), L.ptr(v_t), L.ptr(mean3), L.ptr(std3), b, f, L.ptr(d_hat),
+               L.ptr(d_comp), C.byref(view_of(d_o)), L.stream_ptr())
+        return d_o, None, None, None, None, None, None
+
+
 def correlation(ft4, fr4, v_t, v_r, b, r):
     """CorrelationVGG.correlation_masked_4d (model_dfpn.py:534-565) on NHWC4
     features.  ft4 (B,h,w,C), fr4 (B*R,h,w,C); v_t (B,P)/None, v_r (B*R,P)/None.
