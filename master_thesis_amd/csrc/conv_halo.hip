@@ -8,10 +8,12 @@
 // every input pixel once PER TAP.  Here a block owns an 8 x 16 output-pixel
 // tile of one image: per K chunk of CK input channels it loads the
 // (8+k-1) x (16+k-1) halo patch ONCE, splits it once, and runs all k*k taps out
-// of LDS -- a tap is just a row offset into the halo image.  The per-tap
-// weight tile [BN][CK] (pre-split bf16 planes) is double-buffered through
-// registers; the next chunk's halo loads are in flight during the whole tap
-// loop.  One barrier per tap, two at a chunk boundary.
+// of LDS -- a tap is just a row offset into the halo image.  igemm_halo_kernel
+// copies the per-tap weight tile (a ready LDS image, 16-bit planes) with LDS-DMA,
+// double-buffered, one barrier per tap; igemm_halo_rb_kernel (128 / 64-wide
+// channel tiles, >= 2 K chunks) fetches weight fragments straight into registers
+// and synchronises once per chunk.  The next chunk's halo loads are in flight
+// during the tap loop.
 #include <cstdlib>
 #include "conv_common.h"
 
@@ -66,7 +68,6 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
   constexpr int NCH = TILE_E / 8, RB = (NCH + 255) / 256;
 
   f32x4 rh[RH];
-  bf16x8 rb[RB];
   auto load_halo = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < RH; ++i) {
@@ -89,23 +90,6 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
       }
     }
   };
-#ifdef MT_HALO_REGSTAGE
-  auto load_B = [&](int c0, int tap, int buf) {
-    const __bf16* tile = wt16 + ((long)(tap * nchunk_w + c0 / CK) * ntile_w + blockIdx.y) * TILE_E;
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const int c = tid + 256 * i;
-      if (c < NCH) rb[i] = *reinterpret_cast<const bf16x8*>(tile + c * 8);
-    }
-  };
-  auto store_B = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const int c = tid + 256 * i;
-      if (c < NCH) *reinterpret_cast<bf16x8*>(&sB[buf][0][c * 8]) = rb[i];
-    }
-  };
-#else
   // LDS-DMA: the weight tile in HBM is the LDS image itself, so it is copied
   // global -> LDS directly (wave-uniform LDS base + lane * 16 B), no VGPR round
   // trip and no ds_write; __syncthreads() drains it before the tile is read
@@ -120,8 +104,6 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
                                          16, 0, 0);
     }
   };
-  auto store_B = [&](int) {};
-#endif
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -146,7 +128,6 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
   load_halo(0);
   store_halo();
   load_B(0, 0, 0);
-  store_B(0);
   __syncthreads();
   int it = 0;
   for (int ch = 0; ch < nchunk; ++ch) {
@@ -178,7 +159,6 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
 #pragma unroll
           for (int b = 0; b < TN; ++b) mfma_splitf<NS, FMT>(fa[a], fb[b], acc[a][b]);
       }
-      if (!last || more) store_B(buf ^ 1);
       if (last && more) {
         __syncthreads();                      // every wave is done with this chunk's halo
         store_halo();
