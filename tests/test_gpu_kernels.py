@@ -53,6 +53,12 @@ CONV_CASES = [
     (1, 40, 24, 64, 64, 3, 1, 'c', 2),
     (1, 16, 16, 160, 32, 3, 1, 'c', 2),
     (2, 16, 16, 3, 64, 3, 1, 'c', 1),
+    # ragged tiles for the register-B forward (128- and 64-wide), the 8-row / two-launch weight gradients
+    (1, 13, 19, 128, 128, 5, 1, 'c', 1),
+    (2, 21, 17, 128, 128, 3, 1, 'c', 1),
+    (1, 11, 30, 128, 64, 3, 1, 'c', 2),
+    (1, 9, 7, 128, 128, 3, 2, 't', 0),
+    (1, 19, 23, 64, 128, 5, 2, 'c', 1),
 ]
 
 
