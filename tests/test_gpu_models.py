@@ -311,6 +311,8 @@ def test_pack_registry_follows_the_parameters(mt, dfpn_sd):
     import ctypes
     from master_thesis_amd import engine as E, _lib as L
     from master_thesis_amd.graph import GraphedTrainStep
+    if E.PRECISION == 'f32':
+        pytest.skip('fp32 packs are re-made every epoch, they are not in the registry')
     batch = to_dev(S.synthetic_batch(1, 2, 64, 64, seed=13, flows_use=[True]))
     model = mt.DFPN(mt.VGGFeatures(device=DEV), **KW)
     model.load_state_dict(dfpn_sd)
