@@ -308,16 +308,20 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_rb_kernel(ConvK p, int tile
       // the next chunk's halo: converted into the other image under the last tap's MFMAs
       if (last && more) store_halo(cur ^ 1);
       const int toff = (kh * HW_ + kw) * LD;
+      // all A fragments of the tap (both k-steps) are requested before the first MFMA
+      bf16x8 fa[KSTEPS][TM][NS];
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks) {
-        bf16x8 fa[TM][NS];
+      for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int s = 0; s < NS; ++s)
-            fa[a][s] = *reinterpret_cast<const bf16x8*>(&hb[s * HP * LD + a_base[a] + toff + ks * 16]);
+            fa[ks][a][s] = *reinterpret_cast<const bf16x8*>(&hb[s * HP * LD + a_base[a] + toff + ks * 16]);
+      __builtin_amdgcn_sched_barrier(0);     // (the scheduler would sink every read next to its MFMA)
 #pragma unroll
-        for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(fa[a], fb[ks], acc[a][0]);
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(fa[ks][a], fb[ks], acc[a][0]);
         // this slot's next contents: the same k-step of the next tap
         if (!last) load_B(ch, tap + 1, ks);
         else if (more) load_B(ch + 1, 0, ks);
