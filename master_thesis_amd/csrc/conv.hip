@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(512, 1) void corr_fused_kernel(const float* ft, lon
 #pragma unroll
     for (int i = 0; i < NI; ++i) t[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srT, toff[i], c0 * 4, 0));
 #pragma unroll
-    for (int i = 0; i < NI; ++i) r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srR, roff[i], c0 * 4, 0));
+    for (int i = 0; i < NI; ++i) r[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srR, roff[i], c0 * 4, 2));   // nt: read once
   };
   auto store = [&](const f32x4 (&t)[NI], const f32x4 (&r)[NI], int buf) {
     __bf16* bT = sm + buf * (2 * NS * PL);
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(512, 1) void corr_fused_kernel(const float* ft, lon
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int pr = wn * 128 + b * 32 + li;
-        ob[(long)pt * P + pr] = acc[a][b][r] * f1 * nR[pr];
+        __builtin_nontemporal_store(acc[a][b][r] * f1 * nR[pr], &ob[(long)pt * P + pr]);   // written once, read by a later kernel
       }
     }
 }
