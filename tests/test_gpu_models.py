@@ -420,3 +420,43 @@ def test_g13_cpn_aligner(golden, mt):
     loss = chn.training_step(to_dev(S.synthetic_batch(1, 3, 64, 64, seed=3)), 0)
     loss.backward()
     assert np.isfinite(float(loss)) and all(p.grad is None for p in model.parameters())
+
+
+def test_checkpoint_resume(mt, dfpn_sd, tmp_path):
+    """state_dict round trip (model + FlatAdam): a run resumed from a checkpoint holds exactly the
+    state that was saved (parameters, both Adam moments, step count) and takes the next step like
+    the run that wrote it.  (The two third steps are compared through their loss: a few kernels
+    accumulate with float atomics, and early Adam steps turn rounding-level gradient differences
+    into +-lr parameter differences, so the parameters themselves are not bit-comparable.)"""
+    batch = to_dev(S.synthetic_batch(1, 2, 64, 64, seed=21, flows_use=[True]))
+
+    def fresh():
+        model = mt.DFPN(mt.VGGFeatures(device=DEV), **KW)
+        model.load_state_dict(dfpn_sd)
+        model = model.to(DEV)
+        return model, model.configure_optimizers()['optimizer']
+
+    def step(model, opt):
+        opt.zero_grad()
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    m1, o1 = fresh()
+    step(m1, o1)
+    step(m1, o1)
+    path = tmp_path / 'ckpt.pt'
+    torch.save({'model': m1.state_dict(), 'optimizer': o1.state_dict()}, path)
+    saved = (o1.flat_p.clone(), o1.exp_avg.clone(), o1.exp_avg_sq.clone())
+    loss1 = step(m1, o1)                                # the original run goes on
+    m2, o2 = fresh()
+    ck = torch.load(path, map_location=DEV)
+    assert set(ck['model']) == set(m2.state_dict())
+    m2.load_state_dict(ck['model'])
+    o2.load_state_dict(ck['optimizer'])
+    assert o2.step_count == 2
+    assert torch.equal(o2.flat_p, saved[0]) and torch.equal(o2.exp_avg, saved[1]) and torch.equal(o2.exp_avg_sq, saved[2])
+    loss2 = step(m2, o2)                                # the resumed run takes the same third step
+    np.testing.assert_allclose(loss2, loss1, rtol=1e-4)
+    assert o2.step_count == 3
