@@ -12,9 +12,16 @@
  *   - return 0 on success, a negative mt_status otherwise; no exceptions cross
  *     the ABI; mt_last_error() gives a thread-local message.
  *   - nothing allocates or synchronises: the caller passes workspaces.
- *   - activations inside the engine are "NHWC4": float32, channels innermost
- *     and contiguous, the channel count padded to a multiple of 4 with ZEROS;
- *     image / row / pixel strides are explicit (in floats) so that channel
+ *   - activations inside the engine are "NHWC" engine tensors: float32,
+ *     channels innermost and contiguous, the channel count padded with ZEROS.
+ *     The ABI itself accepts any C % 4 == 0 (mt_view); the LDS halo-tile
+ *     kernels (stride-1 3x3 / 5x5 forward, backward-data and weight gradient,
+ *     i.e. > 90 % of the FLOPs) additionally need C % 8 == 0 -- one 32-byte run
+ *     = one pixel's 8 channels of one tap = one MFMA K group -- and a tensor
+ *     with C % 8 != 0 silently takes the slower implicit-GEMM gather kernel.
+ *     The host side (master_thesis_amd/engine.py: cpad) therefore pads every
+ *     engine tensor to a multiple of 8 (1 -> 8, 3 -> 8, 10 -> 16).
+ *     Image / row / pixel strides are explicit (in floats) so that channel
  *     windows of a wider buffer (dense blocks) and transposed pixel orders
  *     (SeparableConv4d's permute) are addressed in place.
  */
@@ -399,6 +406,45 @@ int mt_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
 int mt_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n,
                      float beta1, float beta2, float eps, float grad_scale,
                      float* state, void* stream);
+
+/* ---- either side of the step: dataset synthesis and validation metrics ----
+ * TransformsUtils.dilate (utils.py:618-640: cv2.dilate, MORPH_CROSS element of kh x kw, odd,
+ * `iterations` times, default border) on the mask planes m (B,1,F,H,W), fused with the masked
+ * fill of dataset.py:168-169, x = (1 - m') * y + m' * fill3[c] on (B,3,F,H,W) tensors
+ * (y = x = fill3 = NULL: dilation only).  iterations * (k / 2) <= 16.  m_out must not alias m. */
+int mt_mask_dilate_fill(const float* m, const float* y, const float* fill3, int32_t B, int32_t F,
+                        int32_t H, int32_t W, int32_t kh, int32_t kw, int32_t iterations,
+                        float* m_out, float* x, void* stream);
+/* MeasuresUtils.psnr (utils.py:407-429 -> skimage 0.18.3 peak_signal_noise_ratio): per image n of
+ * N contiguous images of per_image floats, out[3n..3n+2] = {sum (y_hat - y)^2, min(y), max(y)}
+ * (float32 differences, float64 sum, as skimage); the caller derives data_range from the range of
+ * y and forms 10 log10(data_range^2 / mse).  out: 3 N doubles (initialised here). */
+int mt_psnr_sums(const float* y_hat, const float* y, int32_t N, int64_t per_image, double* out,
+                 void* stream);
+/* MeasuresUtils.ssim (utils.py:431-448 -> skimage 0.18.3 structural_similarity, multichannel):
+ * per plane (image, channel) of H x W floats, out[plane] = sum of the SSIM map over the
+ * (H - win + 1) x (W - win + 1) pixels whose window lies inside the image (skimage crops the rest),
+ * uniform win x win window, sample covariance, float64 arithmetic, C1 = (K1 R)^2, C2 = (K2 R)^2.
+ * out: `planes` doubles (zeroed here). */
+int mt_ssim_sums(const float* a, const float* b, int32_t planes, int32_t H, int32_t W, int32_t win,
+                 double data_range, double K1, double K2, double* out, void* stream);
+
+/* ---- data-parallel gradient exchange (SURVEY.md 5 "distributed comm backend", 8e) ----
+ * The reference has no collective call site: with `--gpus N` Lightning's DDP would
+ * all-reduce the gradients after loss.backward() (model_dfpn.py:135-158,
+ * model_chn.py:256-280 are the steps it wraps).  Here the exchange is one in-place fp32
+ * SUM all-reduce of the flat gradient buffer over an RCCL communicator (xGMI) that the
+ * library owns: one process per GPU, rank 0 calls mt_comm_unique_id and hands the 128
+ * bytes to every rank out of band (torch.distributed's store: bootstrap only), every
+ * rank calls mt_comm_init with its HIP device current.  RCCL is bound at run time from
+ * `rccl_path` (NULL / "" = the loader's default librccl.so.1), so the library and every
+ * other entry point work without it.  mt_allreduce_sum_f32 enqueues on `stream` and
+ * returns; nothing synchronises with the host. */
+int mt_comm_unique_id(const char* rccl_path, void* id128);
+int mt_comm_init(const char* rccl_path, const void* id128, int32_t rank, int32_t world, void** comm);
+int mt_comm_info(void* comm, int32_t* rank, int32_t* world);
+int mt_comm_destroy(void* comm);
+int mt_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

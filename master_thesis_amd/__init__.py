@@ -10,8 +10,8 @@ from .model_vgg import VGGFeatures  # noqa: F401
 from .model_dfpn import DFPN  # noqa: F401
 from .model_chn import CHN  # noqa: F401
 from .model_cpn import CPN  # noqa: F401
-from .utils import FlowsUtils, LossesUtils, MovementsUtils, TransformsUtils  # noqa: F401
+from .utils import FlowsUtils, LossesUtils, MeasuresUtils, MovementsUtils, TransformsUtils  # noqa: F401
 from .optim import FlatAdam  # noqa: F401
 
-__all__ = ['CHN', 'CPN', 'DFPN', 'VGGFeatures', 'FlowsUtils', 'LossesUtils', 'MovementsUtils', 'TransformsUtils',
+__all__ = ['CHN', 'CPN', 'DFPN', 'VGGFeatures', 'FlowsUtils', 'LossesUtils', 'MeasuresUtils', 'MovementsUtils', 'TransformsUtils',
            'FlatAdam']

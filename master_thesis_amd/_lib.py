@@ -115,6 +115,14 @@ SIGNATURES = {
     'mt_sobel_l1_bwd': [_vp, _vp, i32, i32, i32, _vp, _vp, _vp],
     'mt_adam_step': [_vp, _vp, _vp, _vp, i64, f32, f32, f32, f32, f32, f32, _vp],
     'mt_adam_step_dev': [_vp, _vp, _vp, _vp, i64, f32, f32, f32, f32, _vp, _vp],
+    'mt_mask_dilate_fill': [_vp, _vp, _vp, i32, i32, i32, i32, i32, i32, i32, _vp, _vp, _vp],
+    'mt_psnr_sums': [_vp, _vp, i32, i64, _vp, _vp],
+    'mt_ssim_sums': [_vp, _vp, i32, i32, i32, i32, C.c_double, C.c_double, C.c_double, _vp, _vp],
+    'mt_comm_unique_id': [C.c_char_p, _vp],
+    'mt_comm_init': [C.c_char_p, _vp, i32, i32, _P(_vp)],
+    'mt_comm_info': [_vp, _P(i32), _P(i32)],
+    'mt_comm_destroy': [_vp],
+    'mt_allreduce_sum_f32': [_vp, _vp, i64, _vp],
 }
 _RESTYPES = {'mt_last_error': C.c_char_p, 'mt_wgrad_slab_floats': i64, 'mt_weight_pack_halo_elems': i64}
 

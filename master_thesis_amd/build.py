@@ -8,7 +8,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmt355.so')
 SOURCES = [('conv.hip', []), ('conv_halo.hip', []), ('conv_halo_wgrad.hip', []), ('stream.hip', ['-ffp-contract=off']),
-           ('api.cpp', [])]
+           ('metrics.hip', []), ('api.cpp', []), ('comm.cpp', [])]
 
 
 def _stale(target, deps):
@@ -37,10 +37,10 @@ def build(force=False, verbose=True):
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)
-        with ThreadPoolExecutor(max_workers=min(5, len(cmds))) as ex:
+        with ThreadPoolExecutor(max_workers=min(6, len(cmds))) as ex:
             list(ex.map(run, cmds))
     if force or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

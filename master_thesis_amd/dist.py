@@ -1,23 +1,137 @@
 """Data-parallel gradient exchange: one process per GPU, clips
 sharded over ranks, ONE sum-all-reduce per step over the flat fp32 gradient
 buffer of the parameters that actually receive gradients (DFPN 55.7 MB, CHN
-58.8 MB), issued in a few large buckets through torch.distributed (backend
-"nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for the tests).  The 1/world
-averaging is folded into the Adam kernel (FlatAdam.grad_scale)."""
+58.8 MB).  The 1/world averaging is folded into the Adam kernel
+(FlatAdam.grad_scale).
+
+On GPUs the collective goes through the C ABI: libmt355 owns an RCCL
+communicator (``mt_comm_init``: xGMI underneath) and ``mt_allreduce_sum_f32``
+enqueues the buckets on a side HIP stream that waits for the backward through
+an event; the Adam launch waits for the buckets through another.  Nothing
+synchronises with the host.  ``torch.distributed`` is the bootstrap only (it
+carries RCCL's 128-byte unique id to the ranks) -- and the whole transport for
+CPU tensors (gloo: the tests) or when ``MT355_COMM=torch``."""
+import ctypes as C
+import os
+import sys
+
 import torch
 import torch.distributed as dist
 
+from . import _lib as L
+
 BUCKET_FLOATS = 4 * 1024 * 1024      # 16 MB buckets: a handful of large collectives
+_comm = None                         # the process's RcclComm (one GPU per process)
+_comm_failed = None
 
 
 def is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def allreduce_flat_(flat, bucket_floats=BUCKET_FLOATS, async_op=False):
-    """In-place SUM all-reduce of a 1-D tensor in contiguous buckets."""
+def rccl_library_path():
+    """The RCCL build this process already maps (torch's), else the loader default."""
+    p = os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+    return p if os.path.exists(p) else ''
+
+
+class RcclComm:
+    """An RCCL communicator owned by libmt355 + the side stream its collectives run on."""
+
+    def __init__(self, id_bytes, rank, world, device):
+        assert len(id_bytes) == 128
+        self.device = torch.device(device)
+        self.handle = C.c_void_p()
+        buf = C.create_string_buffer(bytes(id_bytes), 128)
+        with torch.cuda.device(self.device):
+            L.call('mt_comm_init', rccl_library_path().encode(), C.cast(buf, C.c_void_p), rank, world, C.byref(self.handle))
+            self.stream = torch.cuda.Stream(device=self.device)
+        r, w = L.i32(), L.i32()
+        L.call('mt_comm_info', self.handle, C.byref(r), C.byref(w))
+        self.rank, self.world = r.value, w.value
+        assert (self.rank, self.world) == (rank, world), (self.rank, self.world, rank, world)
+        self.ready = torch.cuda.Event()
+        self.done = torch.cuda.Event()
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        L.call('mt_comm_unique_id', rccl_library_path().encode(), C.cast(buf, C.c_void_p))
+        return bytes(buf.raw)
+
+    def allreduce_sum_(self, flat, bucket_floats=None):
+        """In-place SUM all-reduce of a 1-D fp32 CUDA tensor: the buckets run on the side stream
+        after everything already queued on the current stream; the current stream continues after
+        the last bucket.  Asynchronous with respect to the host."""
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        bucket_floats = bucket_floats or BUCKET_FLOATS
+        cur = torch.cuda.current_stream(self.device)
+        self.ready.record(cur)
+        self.stream.wait_event(self.ready)
+        n, base = flat.numel(), flat.data_ptr()
+        for off in range(0, n, bucket_floats):
+            k = min(bucket_floats, n - off)
+            L.call('mt_allreduce_sum_f32', self.handle, C.c_void_p(base + 4 * off), k, C.c_void_p(self.stream.cuda_stream))
+        self.done.record(self.stream)
+        cur.wait_event(self.done)
+        flat.record_stream(self.stream)
+
+    def destroy(self):
+        if self.handle:
+            torch.cuda.synchronize(self.device)
+            L.call('mt_comm_destroy', self.handle)
+            self.handle = C.c_void_p()
+
+
+def init_comm(device=None):
+    """Create this rank's RcclComm (idempotent).  Needs an initialised torch.distributed group of
+    any backend for the bootstrap.  Returns None -- after saying why on stderr -- when RCCL cannot
+    be used (MT355_COMM=torch, no CUDA device, RCCL refuses): the exchange then goes through
+    torch.distributed."""
+    global _comm, _comm_failed
+    if _comm is not None or _comm_failed is not None:
+        return _comm
+    if os.environ.get('MT355_COMM', 'rccl') != 'rccl' or not torch.cuda.is_available() or not dist.is_initialized():
+        _comm_failed = 'disabled'
+        return None
+    device = torch.device(device if device is not None else ('cuda', torch.cuda.current_device()))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    try:
+        box = [RcclComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        _comm = RcclComm(box[0], rank, world, device)
+    except Exception as e:       # noqa: BLE001 - every rank must end up on the SAME transport
+        _comm_failed = repr(e)
+        print(f'[mt355] rank {rank}: RCCL communicator unavailable ({e}); using torch.distributed', file=sys.stderr, flush=True)
+    # one rank failing moves everybody to the fallback (a split transport would deadlock)
+    ok = torch.tensor([1 if _comm is not None else 0], device=device if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok) == 0 and _comm is not None:
+        _comm.destroy()
+        _comm, _comm_failed = None, 'another rank failed'
+    return _comm
+
+
+def transport():
+    """'rccl (C ABI)' | 'torch.distributed/<backend>' | 'none': what sync_gradients uses."""
+    if not is_dist():
+        return 'none'
+    return 'rccl (C ABI, mt_allreduce_sum_f32)' if _comm is not None else f'torch.distributed/{dist.get_backend()}'
+
+
+def shutdown():
+    global _comm, _comm_failed
+    if _comm is not None:
+        _comm.destroy()
+    _comm, _comm_failed = None, None
+
+
+def allreduce_flat_(flat, bucket_floats=None, async_op=False):
+    """In-place SUM all-reduce of a 1-D tensor in contiguous buckets through torch.distributed
+    (CPU tensors / the fallback transport)."""
     if not is_dist():
         return []
+    bucket_floats = bucket_floats or BUCKET_FLOATS
     works = []
     for off in range(0, flat.numel(), bucket_floats):
         works.append(dist.all_reduce(flat[off:off + bucket_floats], op=dist.ReduceOp.SUM, async_op=True))
@@ -28,20 +142,26 @@ def allreduce_flat_(flat, bucket_floats=BUCKET_FLOATS, async_op=False):
 
 
 def sync_gradients(optimizer):
-    """Average the gradients of a FlatAdam optimizer across ranks."""
+    """Average the gradients of a FlatAdam optimizer across ranks (sum here, 1/world in Adam)."""
     if not is_dist():
         optimizer.grad_scale = 1.0
         return
-    # The backward (or the replayed step graph) is drained first: the collective then starts
-    # on an idle queue instead of being ordered behind ~1.6 k queued launches through a
-    # cross-stream event (with gloo on CUDA tensors that wait was observed to take seconds).
-    # Cost: one host wake-up per step (tens of microseconds against a ~200 ms step).
-    if optimizer.flat_g.is_cuda:
-        torch.cuda.current_stream().synchronize()
-    allreduce_flat_(optimizer.flat_g)
+    flat = optimizer.flat_g
+    comm = init_comm(flat.device) if flat.is_cuda else None
+    if comm is not None:
+        comm.allreduce_sum_(flat)                 # stream-ordered: no host synchronisation
+    else:
+        if flat.is_cuda and dist.get_backend() != 'nccl':
+            # gloo stages CUDA tensors through the host: drain the backward first so that the
+            # copy does not wait behind ~1.6 k queued launches through a cross-stream event
+            torch.cuda.current_stream().synchronize()
+        allreduce_flat_(flat)
     optimizer.grad_scale = 1.0 / dist.get_world_size()
 
 
 def broadcast_parameters(optimizer, src=0):
+    """Every rank starts from rank ``src``'s parameters."""
     if is_dist():
         dist.broadcast(optimizer.flat_p, src=src)
+        from . import engine as E
+        E.bump_weight_epoch()           # packed weight images made before the broadcast are stale

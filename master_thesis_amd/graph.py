@@ -1,9 +1,25 @@
 """Replay a whole training step (forward + losses + backward [+ Adam]) from ONE
-captured hipGraph: the DFPN / CHN steps are chains of ~250 / ~2500 short
-launches whose Python and launch overhead (19 / 53 ms per step at config 2/3)
-would otherwise sit between the kernels.  The batch lives in static tensors;
-``step(batch)`` copies a new batch in and replays."""
+captured hipGraph: the DFPN / CHN steps are chains of ~660 / ~2300 launches.
+With those counts the eager path is within 1-2 % of the replay on an idle host
+(DESIGN.md section 3); the graph keeps that independent of host jitter, which
+is what matters when 8 ranks wait for each other every step.  The batch lives
+in static tensors; ``step(batch)`` copies a new batch in and replays."""
+import gc
+
 import torch
+
+
+def _live_autograd_tensors():
+    """CUDA tensors that still carry a grad_fn: an autograd graph that survives into the capture
+    would bring its AccumulateGrad nodes (bound to the warm-up stream) along."""
+    out = []
+    for o in gc.get_objects():
+        try:
+            if torch.is_tensor(o) and o.is_cuda and o.grad_fn is not None:
+                out.append(o)
+        except Exception:      # noqa: BLE001 - objects half way through destruction
+            pass
+    return out
 
 
 def _copy_batch_(dst, src):
@@ -27,10 +43,16 @@ class GraphedTrainStep:
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        # nothing of the warm-up steps may survive into the capture: a live autograd
-        # graph would carry AccumulateGrad nodes bound to the side stream
-        import gc
+        # nothing of the warm-up steps may survive into the capture: a live autograd graph would
+        # carry AccumulateGrad nodes bound to the side stream (round-1 GPU faults).  Cycles are
+        # collected, then it is CHECKED: whoever still holds a loss of an earlier step must drop
+        # or detach it (a logger that keeps attached losses, a `last_loss` variable, ...).
         gc.collect()
+        live = _live_autograd_tensors()
+        if live:
+            raise RuntimeError(
+                f'GraphedTrainStep: {len(live)} CUDA tensor(s) from earlier steps still carry an autograd graph '
+                f'(shapes {[tuple(t.shape) for t in live[:4]]}); detach or drop them before capturing')
         # the weight packs must be part of the captured step: with the optimizer in the graph its
         # step re-packs them; without it the graph starts with a re-pack.  The device tables of the
         # batched re-pack are (re)built here, eagerly: a capture cannot copy them from the host.
@@ -47,6 +69,9 @@ class GraphedTrainStep:
             self.loss.backward()
             if include_optimizer:
                 self.opt.step()
+        # the static loss scalar is handed out detached: the captured step's autograd graph must not
+        # outlive the capture (a later capture in the same process would trip over it)
+        self.loss = self.loss.detach()
         if include_optimizer:
             self.opt.step_count -= 1           # capturing records the update, it does not run it
         # the captured launches point at these buffers and tables: they live as long as the graph
@@ -63,6 +88,8 @@ class GraphedTrainStep:
     def step(self, batch=None):
         if batch is not None and batch is not self.batch:
             _copy_batch_(self.batch, batch)
+        if self.include_optimizer:
+            self.opt.sync_device_lr()          # an LR scheduler / a resumed checkpoint changed it
         self.graph.replay()
         if self.include_optimizer:
             self.opt.step_count += 1

@@ -358,10 +358,26 @@ class CHN(LightningModule):
         return loss
 
     def validation_step(self, batch, batch_idx):
-        """model_chn.py:282-307 (PSNR/SSIM/LPIPS logging is out of scope)."""
-        loss, loss_items = self._step(batch)
+        """model_chn.py:282-307: the losses and the PSNR / SSIM (/ LPIPS when a model is given)
+        of the first reference's composite, all of it on the device."""
+        (x, m), y, info = batch
+        t, r_list = CHN.get_indexes(x.size(2))
+        x_ref_aligned, v_ref_aligned, v_map = self.model_aligner.align(
+            x[:, :, t], m[:, :, t], take(x, 2, r_list), take(m, 2, r_list))
+        y_hat, y_hat_comp = self(x[:, :, t], 1 - m[:, :, t], x_ref_aligned, v_ref_aligned, v_map)
+        loss, loss_items = self.compute_loss(y[:, :, t], (1 - m)[:, :, t], y_hat, y_hat_comp, v_map)
         self._log_losses(loss, loss_items, 'validation')
+        self._log_metrics(y_hat_comp[:, :, 0], y[:, :, t], 'validation')
         return loss
+
+    def _log_metrics(self, y_hat_comp, y_target, split):
+        """model_chn.py:408-422."""
+        from .utils import MeasuresUtils
+        with torch.no_grad():
+            self.log('measures_psnr_{}'.format(split), MeasuresUtils.psnr(y_hat_comp, y_target))
+            self.log('measures_ssim_{}'.format(split), MeasuresUtils.ssim(y_hat_comp, y_target))
+            if self.model_lpips is not None:
+                self.log('measures_lpips_{}'.format(split), MeasuresUtils.lpips(y_hat_comp, y_target, self.model_lpips))
 
     # ---- test-time inpainting drivers (model_chn.py:87-254, 309-323): orchestration over the
     # aligner and forward() above; every tensor op stays on the device, the only host reads are

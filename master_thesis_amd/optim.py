@@ -62,23 +62,43 @@ class FlatAdam(torch.optim.Optimizer):
                 self.flat_g[off:off + k].copy_(p.grad.reshape(-1))
                 p.grad = self._grad_view(off, k, p.shape)
 
+    def check_aliasing(self):
+        """Every parameter must still BE its window of the flat buffer (``model.to(dtype)``,
+        ``load_state_dict(assign=True)`` or ``p.data = ...`` silently break that: Adam would then
+        update a buffer nobody reads).  A parameter that moved is re-adopted: its values are copied
+        into the window, ``p.data`` points back at it and the packed weight images are refreshed."""
+        moved = 0
+        for p, (off, k) in zip(self._plist, self._slices):
+            if p.data_ptr() != self.flat_p.data_ptr() + 4 * off:
+                assert p.numel() == k, 'a parameter changed its size under FlatAdam'
+                self.flat_p[off:off + k].copy_(p.detach().reshape(-1).to(self.flat_p))
+                p.data = self.flat_p[off:off + k].view(p.shape)
+                moved += 1
+        if moved:
+            E.bump_weight_epoch()
+        return moved
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        capturing = self.flat_p.is_cuda and torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            self.check_aliasing()
         self._gather_foreign_grads()
         g = self.param_groups[0]
         b1, b2 = g['betas']
         self.step_count += 1
-        if torch.cuda.is_current_stream_capturing():
+        if capturing:
             # graph capture: step and lr are read from the device at replay time
             L.call('mt_adam_step_dev', L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.exp_avg),
                    L.ptr(self.exp_avg_sq), self.flat_p.numel(), b1, b2, g['eps'], self.grad_scale,
                    L.ptr(self.dev_state), L.stream_ptr())
         else:
             self.dev_state[0] = float(self.step_count)
+            self.sync_device_lr()
             bc1 = 1.0 - b1 ** self.step_count
             bc2 = 1.0 - b2 ** self.step_count
             L.call('mt_adam_step', L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.exp_avg),
@@ -88,16 +108,50 @@ class FlatAdam(torch.optim.Optimizer):
         return loss
 
     def sync_device_lr(self):
-        """Call after an LR-scheduler step when the update runs from a graph."""
-        self.dev_state[1] = float(self.param_groups[0]['lr'])
+        """Device copy of the learning rate (read by the graph-captured update).  Called by
+        step() and by GraphedTrainStep before every replay, so an LR scheduler or a resumed
+        checkpoint needs no extra call."""
+        lr = float(self.param_groups[0]['lr'])
+        if lr != getattr(self, '_dev_lr', None):
+            self.dev_state[1] = lr
+            self._dev_lr = lr
+
+    def sync_device_state(self):
+        """Device copies of {step, lr} from the host-side state (after load_state_dict)."""
+        self.dev_state[0] = float(self.step_count)
+        self._dev_lr = None
+        self.sync_device_lr()
 
     def state_dict(self):
         return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
                 'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
-        self.step_count = sd['step']
-        self.exp_avg.copy_(sd['exp_avg'])
-        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        """Accepts FlatAdam's own layout and the ``torch.optim.Adam`` layout of reference /
+        Lightning checkpoints (``state`` = {index: {step, exp_avg, exp_avg_sq}} over the same
+        parameter order, ``param_groups``).  The device-resident {step, lr} follow."""
+        if 'state' in sd and 'exp_avg' not in sd:
+            st = sd['state']
+            if len(st) not in (0, len(self._plist)):
+                raise ValueError(f'optimizer state holds {len(st)} parameters, this model trains {len(self._plist)}: '
+                                 'the checkpoint was written for a different set of trainable parameters '
+                                 '(the reference also hands the frozen VGG / aligner to Adam)')
+            steps = set()
+            for i, (off, k) in enumerate(self._slices):
+                ent = st.get(i, st.get(str(i)))
+                if ent is None:
+                    continue
+                self.exp_avg[off:off + k].copy_(ent['exp_avg'].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(ent['exp_avg_sq'].reshape(-1))
+                steps.add(int(ent['step']))
+            if len(steps) > 1:
+                raise ValueError(f'per-parameter step counts differ ({sorted(steps)}): one fused update needs one')
+            self.step_count = steps.pop() if steps else 0
+        else:
+            self.step_count = int(sd['step'])
+            self.exp_avg.copy_(sd['exp_avg'])
+            self.exp_avg_sq.copy_(sd['exp_avg_sq'])
         for g, s in zip(self.param_groups, sd['param_groups']):
-            g.update(s)
+            g.update({k: v for k, v in s.items() if k != 'params'})
+        self.sync_device_state()
+        E.bump_weight_epoch()

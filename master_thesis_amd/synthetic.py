@@ -25,15 +25,21 @@ def make_batch(b, f, h, w, device, seed=1234):
             dy, dx = (int(v) for v in torch.randint(-3, 4, (2,), generator=gen))
             ya, xa = min(max(0, y0 + dy), h - mh), min(max(0, x0 + dx), w - mw)
             m[i, 0, j, ya:ya + mh, xa:xa + mw] = 1
-    # four cross-shaped 3x3 dilations
-    mm = m.reshape(b * f, 1, h, w)
-    for _ in range(4):
-        p = F.pad(mm, (1, 1, 1, 1))
-        mm = torch.stack([p[:, :, 1:-1, 1:-1], p[:, :, :-2, 1:-1], p[:, :, 2:, 1:-1], p[:, :, 1:-1, :-2],
-                          p[:, :, 1:-1, 2:]]).amax(0)
-    m = mm.reshape(b, 1, f, h, w)
-    fill = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1, 1)
-    x = (1 - m) * y + m * fill
+    if torch.device(device).type == 'cuda':
+        # the dataset's mask dilation + masked fill (dataset.py:158-169) as ONE HIP launch on the device
+        from .utils import TransformsUtils
+        y, m = y.to(device), m.to(device)
+        m, x = TransformsUtils.dilate_fill(m, y, (3, 3), 4)
+    else:
+        # (CPU tensors for the host-side tests: four cross-shaped 3x3 dilations with torch ops)
+        mm = m.reshape(b * f, 1, h, w)
+        for _ in range(4):
+            p = F.pad(mm, (1, 1, 1, 1))
+            mm = torch.stack([p[:, :, 1:-1, 1:-1], p[:, :, :-2, 1:-1], p[:, :, 2:, 1:-1], p[:, :, 1:-1, :-2],
+                              p[:, :, 1:-1, 2:]]).amax(0)
+        m = mm.reshape(b, 1, f, h, w)
+        fill = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1, 1)
+        x = (1 - m) * y + m * fill
     flows_use = torch.tensor([i % 2 == 0 for i in range(b)])
     p = torch.rand((b * f, 4), generator=gen) * 2 - 1
     ang, sc = p[:, 0] * 0.2, 1 + p[:, 1] * 0.1

@@ -2,8 +2,11 @@
 mt355 kernels.  Same names, argument meaning and return layouts as
 ``master_thesis/utils.py`` (cited per method); every tensor lives on the GPU.
 """
+import ctypes as C
+
 import torch
 
+from . import _lib as L
 from . import ops
 
 
@@ -59,6 +62,80 @@ class TransformsUtils:
             return x_target, m_target, x_ref, m_ref
         return (ops.resize_planar(x_target, size, 'bilinear'), ops.resize_planar(m_target, size, 'nearest'),
                 ops.resize_planar(x_ref, size, 'bilinear'), ops.resize_planar(m_ref, size, 'nearest'))
+
+
+    @staticmethod
+    def dilate(images, filter_size, iterations):
+        """utils.py:618-640 (cv2.dilate with a MORPH_CROSS element, ``iterations`` times) on the
+        device: images (1,F,H,W) -- or any (B,1,F,H,W) batch of mask planes -- one fused launch."""
+        return TransformsUtils.dilate_fill(images, None, filter_size, iterations)[0]
+
+    @staticmethod
+    def dilate_fill(m, y, filter_size, iterations, fill=(0.485, 0.456, 0.406)):
+        """The mask half of MasterThesisDataset.__getitem__ (dataset.py:158-169) in ONE launch:
+        m' = dilate(m), x = (1 - m') * y + m' * fill.  m (1,F,H,W) with y (3,F,H,W), or batched
+        (B,1,F,H,W) with (B,3,F,H,W); y = None: dilation only.  Returns (m', x or None)."""
+        assert m.is_cuda and m.dtype == torch.float32
+        batched = m.dim() == 5
+        m5 = (m if batched else m.unsqueeze(0)).contiguous()
+        b, one, f, h, w = m5.shape
+        assert one == 1
+        kw, kh = (filter_size, filter_size) if isinstance(filter_size, int) else filter_size   # cv2 sizes are (w, h)
+        m_out = torch.empty_like(m5)
+        x = fill_t = y5 = None
+        if y is not None:
+            y5 = (y if batched else y.unsqueeze(0)).contiguous()
+            assert y5.shape == (b, 3, f, h, w) and y5.dtype == torch.float32
+            x = torch.empty_like(y5)
+            fill_t = torch.as_tensor(fill, dtype=torch.float32, device=m.device).contiguous()
+        L.call('mt_mask_dilate_fill', L.ptr(m5), L.ptr(y5), L.ptr(fill_t), b, f, h, w, int(kh), int(kw), int(iterations),
+               L.ptr(m_out), L.ptr(x), L.stream_ptr())
+        if not batched:
+            m_out, x = m_out[0], (x[0] if x is not None else None)
+        return m_out, x
+
+
+class MeasuresUtils:
+    """utils.py:404-463: validation metrics, kept on the device (the reference moves every image to
+    the host and calls scikit-image 0.18.3).  Both return 0-d float64 device tensors: nothing
+    synchronises until the logger reads them.  LPIPS stays external (an AlexNet the caller owns)."""
+
+    @staticmethod
+    def psnr(y_hat, y):
+        """utils.py:407-429 -> skimage peak_signal_noise_ratio(y[f], y_hat[f]) per image: the
+        ground truth is image_true; data_range = 1 when min(y) >= 0, else 2 (float images);
+        NaN items count as 100, infinite ones (identical images) are dropped from the mean."""
+        assert y_hat.shape == y.shape and y.dim() == 4
+        y_hat, y = y_hat.contiguous().float(), y.contiguous().float()
+        n = y.shape[0]
+        out = torch.empty((n, 3), device=y.device, dtype=torch.float64)
+        L.call('mt_psnr_sums', L.ptr(y_hat), L.ptr(y), n, y[0].numel(), L.ptr(out), L.stream_ptr())
+        mse = out[:, 0] / float(y[0].numel())
+        data_range = torch.where(out[:, 1] >= 0, 1.0, 2.0).to(torch.float64)
+        items = 10 * torch.log10(data_range ** 2 / mse)
+        items = torch.where(torch.isnan(items), torch.full_like(items, 100.0), items)
+        keep = torch.isfinite(items)
+        return torch.where(keep, items, torch.zeros_like(items)).sum() / keep.sum()
+
+    @staticmethod
+    def ssim(y_hat, y, win_size=7, K1=0.01, K2=0.03):
+        """utils.py:431-448 -> skimage structural_similarity(..., multichannel=True) per image:
+        uniform 7x7 window, sample covariance, float64, data_range = 2 for float images (skimage
+        0.18.3 takes dmax - dmin of the dtype), mean of the map over the pixels whose window lies
+        inside the image, mean over channels, mean over images."""
+        assert y_hat.shape == y.shape and y.dim() == 4
+        y_hat, y = y_hat.contiguous().float(), y.contiguous().float()
+        n, c, h, w = y.shape
+        out = torch.empty((n * c,), device=y.device, dtype=torch.float64)
+        L.call('mt_ssim_sums', L.ptr(y), L.ptr(y_hat), n * c, h, w, int(win_size), 2.0, float(K1), float(K2), L.ptr(out),
+               L.stream_ptr())
+        return (out / float((h - win_size + 1) * (w - win_size + 1))).mean()
+
+    @staticmethod
+    def lpips(y_hat, y, model=None):
+        """utils.py:450-463 (the network is the caller's; its forward runs wherever it lives)."""
+        with torch.no_grad():
+            return model.forward(2 * y_hat - 1, 2 * y - 1).flatten().mean()
 
 
 class LossesUtils:

@@ -53,3 +53,71 @@ def test_two_rank_gradient_allreduce():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def _worker_flat_adam(rank, world, port, out):
+    """The real FlatAdam + the real sync_gradients on CPU tensors (gloo)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from master_thesis_amd import dist as mdist
+    from master_thesis_amd.optim import FlatAdam
+    torch.manual_seed(7 + rank)                      # ranks start from DIFFERENT parameters
+    params = [torch.nn.Parameter(torch.randn(5, 3, 3, 3)), torch.nn.Parameter(torch.randn(5)),
+              torch.nn.Parameter(torch.randn(33, 7))]
+    opt = FlatAdam(params, lr=1e-3)
+    mdist.broadcast_parameters(opt)
+    gathered = [torch.empty_like(opt.flat_p) for _ in range(world)]
+    dist.all_gather(gathered, opt.flat_p)
+    ok = torch.equal(gathered[0], gathered[1])       # ... and agree after the broadcast
+    ok = ok and all(p.data_ptr() == opt.flat_p.data_ptr() + 4 * off for p, (off, k) in zip(params, opt._slices))
+    g = torch.Generator().manual_seed(100 + rank)
+    for p in params:                                 # "backward": a rank-local gradient in the flat windows
+        p.grad.copy_(torch.rand(p.shape, generator=g))
+    local = opt.flat_g.clone()
+    mdist.BUCKET_FLOATS = 100                        # several buckets, ragged tail
+    mdist.sync_gradients(opt)
+    both = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    ok = ok and torch.allclose(opt.flat_g * opt.grad_scale, (both[0] + both[1]) / 2) and opt.grad_scale == 0.5
+    ok = ok and mdist.transport() == 'torch.distributed/gloo'
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sync_gradients_with_flat_adam():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_flat_adam, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def test_flat_adam_state_dict_layouts():
+    """load_state_dict accepts FlatAdam's own layout and torch.optim.Adam's (reference / Lightning
+    checkpoints), restores the device-side {step, lr}, and re-adopts a parameter that was moved."""
+    from master_thesis_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(6))]
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=5e-4)
+    for p in ref.param_groups[0]['params']:
+        p.grad = torch.randn_like(p)
+    ref.step()
+    ref.step()
+    opt = FlatAdam(ps, lr=1e-3)
+    opt.load_state_dict(ref.state_dict())
+    assert opt.step_count == 2 and opt.param_groups[0]['lr'] == 5e-4
+    assert opt.dev_state.tolist() == [2.0, 5e-4] or abs(opt.dev_state[1].item() - 5e-4) < 1e-10
+    st = ref.state_dict()['state']
+    assert torch.equal(opt.exp_avg[:12].view(4, 3), st[0]['exp_avg']) and torch.equal(opt.exp_avg_sq[12:], st[1]['exp_avg_sq'])
+    opt2 = FlatAdam([torch.nn.Parameter(p.detach().clone()) for p in ps], lr=1e-3)
+    opt2.load_state_dict(opt.state_dict())
+    assert opt2.step_count == 2 and torch.equal(opt2.exp_avg, opt.exp_avg) and float(opt2.dev_state[0]) == 2.0
+    # a parameter that no longer aliases the flat buffer is re-adopted
+    ps[1].data = ps[1].data.clone() * 2
+    assert opt.check_aliasing() == 1
+    assert ps[1].data_ptr() == opt.flat_p.data_ptr() + 4 * 12 and torch.equal(opt.flat_p[12:], ps[1].detach().reshape(-1))
+    try:
+        opt.load_state_dict({'state': {0: {}}, 'param_groups': ref.state_dict()['param_groups']})
+        raise AssertionError('a state dict over a different parameter set must be refused')
+    except ValueError:
+        pass

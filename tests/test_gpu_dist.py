@@ -1,0 +1,111 @@
+"""The data-parallel step on real kernels.  One MI355X is enough for the logic: two ranks share
+the card over gloo (CUDA tensors staged through the host); with >= 2 devices the same test runs
+over nccl = RCCL with the gradient exchange behind the C ABI (mt_allreduce_sum_f32).  A
+world-size-1 RCCL communicator exercises the C-ABI plumbing on any box."""
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+KW = dict(lr=1e-4, lr_scheduler_step_size=50, lr_scheduler_gamma=0.5)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _rank(rank, world, port, backend, out):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(here, 'golden')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import seeded as S
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    ndev = torch.cuda.device_count()
+    dev = torch.device('cuda', rank % ndev)
+    torch.cuda.set_device(dev)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    import master_thesis_amd as mt
+    from master_thesis_amd import dist as mdist
+    model = mt.DFPN(mt.VGGFeatures(device=dev), **KW)
+    sd = S.add_buffers(S.seeded_state_dict(S.dfpn_shapes(), seed=rank))     # ranks start apart ...
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    opt = model.configure_optimizers()['optimizer']
+    mdist.broadcast_parameters(opt)                                         # ... and agree after the broadcast
+    (x, m), y, info = S.synthetic_batch(2, 2, 64, 64, seed=31)             # clip r belongs to rank r
+    sl = slice(rank, rank + 1)
+    batch = ((x[sl].to(dev), m[sl].to(dev)), y[sl].to(dev),
+             tuple(i[sl].to(dev) if torch.is_tensor(i) else i for i in info))
+    opt.zero_grad()
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    local = opt.flat_g.clone()
+    mdist.sync_gradients(opt)                       # the real exchange (RCCL through the C ABI on nccl)
+    flat = (opt.flat_g * opt.grad_scale).clone()
+    both = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    want = sum(both) / world
+    err = float((flat - want).abs().max() / want.abs().max())
+    opt.step()
+    ps = [torch.empty_like(opt.flat_p) for _ in range(world)]
+    dist.all_gather(ps, opt.flat_p)
+    same = all(torch.equal(ps[0], p) for p in ps[1:])
+    out[rank] = (err, bool(same), float(local.norm()), mdist.transport())
+    mdist.shutdown()
+    dist.destroy_process_group()
+
+
+def _run(world, backend):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rank, args=(world, _free_port(), backend, out), nprocs=world, join=True)
+    res = dict(out)
+    assert len(res) == world
+    for r, (err, same, norm, transport) in res.items():
+        assert norm > 0 and err < 1e-6 and same, (r, err, same, norm)
+    return res
+
+
+def test_two_ranks_one_card_gloo():
+    """DP step on HIP kernels: the exchanged flat gradient is the mean of the ranks' own gradients
+    and every rank holds the same parameters after Adam."""
+    res = _run(2, 'gloo')
+    assert res[0][3] == 'torch.distributed/gloo'
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs')
+def test_two_ranks_two_cards_rccl_c_abi():
+    res = _run(2, 'nccl')
+    assert res[0][3].startswith('rccl')
+
+
+def test_rccl_communicator_world_size_one():
+    """mt_comm_unique_id / mt_comm_init / mt_allreduce_sum_f32 / mt_comm_destroy on one GPU: a
+    one-rank all-reduce leaves the buffer unchanged and is ordered with the streams around it."""
+    from master_thesis_amd import _lib as L
+    from master_thesis_amd import dist as mdist
+    torch.cuda.set_device(0)
+    comm = mdist.RcclComm(mdist.RcclComm.unique_id(), 0, 1, 'cuda:0')
+    assert (comm.rank, comm.world) == (0, 1)
+    x = torch.arange(5_000_000, device='cuda:0', dtype=torch.float32)
+    y = x * 2                                    # queued on the current stream before the collective
+    comm.allreduce_sum_(y, bucket_floats=1_000_000)
+    z = y + 1                                    # queued after it: must see the reduced buffer
+    torch.cuda.synchronize()
+    assert torch.equal(z, x * 2 + 1)
+    with pytest.raises(L.MT355Error):
+        L.call('mt_allreduce_sum_f32', None, L.ptr(y), 10, L.stream_ptr())
+    comm.destroy()

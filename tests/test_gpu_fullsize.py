@@ -1,0 +1,120 @@
+"""Parity at the sizes the benchmark runs (BASELINE configs 2, 3 and the shape class of 5), where
+the small fixtures say nothing: the 8192-image SeparableConv4d batch with R = 4 group addressing,
+> 2 GB activations, 64-bit offsets, and the 512 -> 256 -> 512 resize route of config 5."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import seeded as S
+from oracle import ref_torch as O
+
+pytestmark = pytest.mark.gpu
+KW = dict(lr=1e-4, lr_scheduler_step_size=50, lr_scheduler_gamma=0.5)
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def to_dev(batch):
+    (x, m), y, info = batch
+    return (x.to(DEV), m.to(DEV)), y.to(DEV), tuple(i.to(DEV) if torch.is_tensor(i) else i for i in info)
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.fixture(scope='module')
+def models():
+    import master_thesis_amd as mt
+    mt._lib.load()
+    sd = S.add_buffers(S.seeded_state_dict(S.chn_shapes()), ('', 'model_aligner.'))
+    vgg = mt.VGGFeatures(device=DEV)
+    dfpn = mt.DFPN(vgg, **KW)
+    chn = mt.CHN(vgg, None, dfpn, **KW)
+    chn.load_state_dict(sd)
+    chn = chn.to(DEV)
+    dsd = {k[len('model_aligner.'):]: v for k, v in sd.items() if k.startswith('model_aligner.')}
+    return mt, dfpn, chn, dsd, sd
+
+
+def test_cfg5_shape_class_vs_oracle(models):
+    """frames_n = 7, 512 x 512 (config 5's shape class, one clip): the inputs go 512 -> 256 for the
+    networks (model_dfpn.py:74-77), the flow goes 256 -> 512 (:100-101), the warp and the CHN run at
+    512.  Forward outputs and every loss item of both steps against the oracle."""
+    mt, dfpn, chn, dsd, sd = models
+    batch = S.synthetic_batch(1, 7, 512, 512, seed=55)
+    (x, m), y, info = batch
+    g = to_dev(batch)
+    (xg, mg), yg, ig = g
+    t, r = dfpn.get_indexes(7)
+    assert (t, r) == (3, [0, 1, 2, 4, 5, 6])
+    torch.set_num_threads(os.cpu_count() or 1)
+    with torch.no_grad():
+        corr, f16, f64, flow = dfpn(xg[:, :, t].contiguous(), mg[:, :, t].contiguous(), xg[:, :, r], mg[:, :, r])
+        rc, r16, r64, rflow = O.dfpn_forward(dsd, x[:, :, t], m[:, :, t], x[:, :, r], m[:, :, r])
+        assert flow.shape == (1, 6, 512, 512, 2)
+        for name, a, b in (('corr', corr, rc), ('flow_16', f16, r16), ('flow_64', f64, r64), ('flow', flow, rflow)):
+            assert rel(a, b) <= 1e-3, (name, rel(a, b))
+        xa, va, vmap = dfpn.align(xg[:, :, t].contiguous(), mg[:, :, t].contiguous(), xg[:, :, r], mg[:, :, r])
+        rxa, rva, rvmap = O.dfpn_align(dsd, x[:, :, t], m[:, :, t], x[:, :, r], m[:, :, r])
+        # nearest-warped visibility: a handful of pixels sit on rounding ties of the flow
+        assert float((va.cpu() != rva).float().mean()) < 1e-3
+        assert float((xa.cpu() - rxa).abs().mean()) < 1e-4
+        loss, items = dfpn._step(g, 4)
+        rloss, ritems = O.dfpn_training_step(dsd, batch)
+        np.testing.assert_allclose([float(i) for i in items], [float(i) for i in ritems], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(float(loss), float(rloss), rtol=1e-3)
+        loss_c, items_c = chn._step(g)
+        rloss_c, ritems_c = O.chn_training_step(sd, batch)
+        np.testing.assert_allclose([float(i) for i in items_c], [float(i) for i in ritems_c], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(float(loss_c), float(rloss_c), rtol=1e-3)
+
+
+def test_cfg2_cfg3_benchmarked_batch_vs_oracle():
+    """The exact batch bench.py times (batch 8, frames_n 5, 256 x 256, make_batch seed 1234, the
+    benchmark's default-initialised weights): every loss item of the DFPN and the CHN step within
+    1e-3 of the oracle -- the same check bench.py attaches to its JSON line."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import master_thesis_amd as mt
+    from master_thesis_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    vgg = mt.VGGFeatures(device=DEV)
+    dfpn = mt.DFPN(vgg, **KW).to(DEV)
+    chn = mt.CHN(vgg, None, dfpn, **KW).to(DEV)
+    batch = make_batch(8, 5, 256, 256, DEV, seed=1234)
+    for kind, model in (('dfpn', dfpn), ('chn', chn)):
+        res = bench.loss_check(kind, model, batch)
+        assert res['ok'], (kind, res['rel_err'])
+
+
+def test_graph_replay_equals_eager_at_benchmark_size():
+    """hipGraph replay of forward + losses + backward == the eager step on the benchmarked batch
+    (B = 8, F = 5, 256 x 256): same loss, same flat gradient."""
+    import master_thesis_amd as mt
+    from master_thesis_amd.graph import GraphedTrainStep
+    from master_thesis_amd.synthetic import make_batch
+    batch = make_batch(8, 5, 256, 256, DEV, seed=1234)
+
+    def fresh():
+        torch.manual_seed(0)
+        model = mt.DFPN(mt.VGGFeatures(device=DEV), **KW).to(DEV)
+        return model, model.configure_optimizers()['optimizer']
+
+    m_e, o_e = fresh()
+    o_e.zero_grad()
+    loss_e = m_e.training_step(batch, 0)
+    loss_e.backward()
+    loss_e, g_e = float(loss_e), o_e.flat_g.clone()
+    del m_e, o_e
+    torch.cuda.empty_cache()
+    m_g, o_g = fresh()
+    g = GraphedTrainStep(m_g, o_g, batch, include_optimizer=False, warmup=1)
+    for _ in range(2):
+        loss_g = g.step()
+    np.testing.assert_allclose(float(loss_g), loss_e, rtol=1e-5)
+    assert float((g_e - o_g.flat_g).norm() / g_e.norm()) < 1e-4
