@@ -36,6 +36,7 @@ class GraphedTrainStep:
         self.model, self.opt = model, optimizer
         self.batch = example_batch
         self.include_optimizer = include_optimizer
+        before = {id(t) for t in _live_autograd_tensors()}     # (the caller's own business)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):          # warm-up on a side stream (allocator, lazy inits)
@@ -45,13 +46,14 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         # nothing of the warm-up steps may survive into the capture: a live autograd graph would
         # carry AccumulateGrad nodes bound to the side stream (round-1 GPU faults).  Cycles are
-        # collected, then it is CHECKED: whoever still holds a loss of an earlier step must drop
-        # or detach it (a logger that keeps attached losses, a `last_loss` variable, ...).
+        # collected, then it is CHECKED: a tensor with a grad_fn that appeared during the warm-up and
+        # is still alive (a logger that keeps attached losses, a hook that stores activations, ...)
+        # must be dropped or detached by whoever holds it.
         gc.collect()
-        live = _live_autograd_tensors()
+        live = [t for t in _live_autograd_tensors() if id(t) not in before]
         if live:
             raise RuntimeError(
-                f'GraphedTrainStep: {len(live)} CUDA tensor(s) from earlier steps still carry an autograd graph '
+                f'GraphedTrainStep: {len(live)} CUDA tensor(s) of the warm-up steps still carry an autograd graph '
                 f'(shapes {[tuple(t.shape) for t in live[:4]]}); detach or drop them before capturing')
         # the weight packs must be part of the captured step: with the optimizer in the graph its
         # step re-packs them; without it the graph starts with a re-pack.  The device tables of the

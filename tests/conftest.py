@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run via gpurun)')
 
 
+@pytest.fixture(scope='session', autouse=True)
+def _cpu_threads():
+    """The CPU oracle runs on the cores this process may really use (affinity + cgroup quota): on
+    the GPU box os.cpu_count() is the whole machine and over-subscribing the share is many times
+    slower."""
+    import torch
+    import bench
+    torch.set_num_threads(bench.host_cores())
+
+
 @pytest.fixture(scope='session')
 def golden():
     import numpy as np

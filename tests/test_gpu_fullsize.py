@@ -52,7 +52,9 @@ def test_cfg5_shape_class_vs_oracle(models):
     (xg, mg), yg, ig = g
     t, r = dfpn.get_indexes(7)
     assert (t, r) == (3, [0, 1, 2, 4, 5, 6])
-    torch.set_num_threads(os.cpu_count() or 1)
+    sys.path.insert(0, ROOT)
+    import bench
+    torch.set_num_threads(bench.host_cores())        # (the cgroup share, not the machine's core count)
     with torch.no_grad():
         corr, f16, f64, flow = dfpn(xg[:, :, t].contiguous(), mg[:, :, t].contiguous(), xg[:, :, r], mg[:, :, r])
         rc, r16, r64, rflow = O.dfpn_forward(dsd, x[:, :, t], m[:, :, t], x[:, :, r], m[:, :, r])
