@@ -232,9 +232,11 @@ typedef struct {
   int32_t BP_total, b_off;   /* MT_PACK_HALO: stacked K parts (BP_total == BP, b_off == 0 for a plain pack) */
   int32_t frag_order;   /* MT_PACK_HALO: mt_weight_pack_halo_frag_order(AP, BP_total, precision) */
 } mt_pack_job;
-/* 1 when mt_weight_pack_halo writes MFMA-fragment order for this shape (the register-B
- * kernel's layout) rather than LDS tile images; the kernels choose by the same rule. */
-int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, int32_t precision);
+/* Layout mt_weight_pack_halo writes for this shape: 0 = LDS tile images, 1 = MFMA-fragment
+ * order (the register-B kernel), 2 = fragment order of the 1-D Winograd F(2,3) transformed
+ * weights G g (3 x 3 layers, T = 9: 12 (kernel row, xi) "taps"); the kernels choose by the
+ * same rule. */
+int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, int32_t T, int32_t precision);
 /* jobs_dev: njobs entries in device memory; equivalent to calling the single-pack
  * entry point of every job.  jobs_host: the same table in host memory (argument checks). */
 int mt_weight_pack_jobs(const mt_pack_job* jobs_dev, const mt_pack_job* jobs_host, int32_t njobs, void* stream);

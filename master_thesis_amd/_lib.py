@@ -89,7 +89,7 @@ SIGNATURES = {
     'mt_absmax': [_P(View), _vp, _vp],
     'mt_absmax_segments': [_vp, i32, _vp],
     'mt_weight_pack_jobs': [_vp, _vp, i32, _vp],
-    'mt_weight_pack_halo_frag_order': [i32, i32, i32],
+    'mt_weight_pack_halo_frag_order': [i32, i32, i32, i32],
     'mt_absmax_flat': [_vp, i64, _vp, _vp],
     'mt_weight_pack_halo_elems': [i32, i32, i32, i32],
     'mt_pad_vector': [_vp, i32, _vp, i32, _vp],

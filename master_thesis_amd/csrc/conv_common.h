@@ -96,6 +96,88 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[TM]
   igemm_epilogue_map<TM, TN>(p, pm, acc, m0, n0, wm, wn, li, lh);
 }
 
+// Fused epilogue of the halo-tile kernels for ONE lane: its output channel ``o`` is fixed, its NE
+// values v[e] (accumulator * 1/scale) belong to the pixels (oy[e], ox[e]) = pix(e) of image n.
+//   v = act(v + bias[o]) * alpha;  v += beta * R;  v += Y (accumulate);  v *= act'(D) for o >= dact_c0
+// Everything that does not depend on the element is hoisted (the bias value, the image bases, the
+// kernel-uniform switches), element offsets are 32-bit, and the optional operands are read in
+// batches (all loads of a pass are in flight together) instead of one dependent load per element.
+// Returns max |v| over what was written.
+template <bool PRED, int NE, class PixFn>
+__device__ __forceinline__ float halo_epilogue_body(const ConvK& p, int n, int o, float (&v)[NE], PixFn pix,
+                                                    unsigned long long okm) {
+  float* yb = p.y + ((long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + o);
+  const int ysh = (int)p.ysh, ysw = (int)p.ysw;
+  auto ok = [&](int e) { return !PRED || ((okm >> e) & 1); };
+  if (p.res) {
+    const float* rb = p.res + ((long)n * p.rsn + o);
+    const int rsh = (int)p.rsh, rsw = (int)p.rsw;
+    float t[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      int oy, ox;
+      pix(e, oy, ox);
+      t[e] = ok(e) ? rb[oy * rsh + ox * rsw] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] += p.beta * t[e];
+  }
+  if (p.accumulate) {
+    float t[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      int oy, ox;
+      pix(e, oy, ox);
+      t[e] = ok(e) ? yb[oy * ysh + ox * ysw] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] += t[e];
+  }
+  if (p.ds && o >= p.dact_c0) {
+    const float* db = p.ds + ((long)n * p.dsn + o);
+    const int dsh = (int)p.dsh, dsw = (int)p.dsw;
+    float t[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      int oy, ox;
+      pix(e, oy, ox);
+      t[e] = ok(e) ? db[oy * dsh + ox * dsw] : 1.f;
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] *= mt_dact_fn(t[e], p.dact);
+  }
+  float vmax = 0.f;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    int oy, ox;
+    pix(e, oy, ox);
+    if (ok(e)) {
+      yb[oy * ysh + ox * ysw] = v[e];
+      vmax = fmaxf(vmax, fabsf(v[e]));
+    }
+  }
+  return vmax;
+}
+
+template <int NE, class PixFn>
+__device__ __forceinline__ float halo_epilogue(const ConvK& p, int n, int o, float (&v)[NE], PixFn pix) {
+  static_assert(NE <= 64, "one mask word");
+  const bool lane_ok = o < p.Co;
+  const float bv = (p.bias && lane_ok) ? p.bias[o] : 0.f;
+  unsigned long long okm = 0;                      // bit e: element e is inside the output
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    int oy, ox;
+    pix(e, oy, ox);
+    if (lane_ok && oy < p.Ho && ox < p.Wo) okm |= 1ull << e;
+    v[e] = mt_act_fn(v[e] + bv, p.act) * p.alpha;
+  }
+  constexpr unsigned long long FULL = NE == 64 ? ~0ull : ((1ull << (NE & 63)) - 1);
+  // interior tiles (almost all of them): no per-element predicate anywhere
+  if (__all(okm == FULL)) return halo_epilogue_body<false, NE>(p, n, o, v, pix, okm);
+  return halo_epilogue_body<true, NE>(p, n, o, v, pix, okm);
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -226,6 +308,46 @@ inline int fill_convk(const mt_conv* d, ConvK* k) {
 
 
 }  // namespace
+
+// Winograd F(2,3) weights of igemm_halo_wino_kernel in MFMA fragment order:
+// dst[tap 12 = ky*4 + xi][chunk][ntile][wn WN][kstep 2][plane 2][lane 64][8], lane (li, lh) holds
+// U[ky][xi][a = (ntile*WN + wn)*32 + li][b = chunk*32 + kstep*16 + 8*lh + j],  U = G g[ky][:]:
+// (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) over the kernel row ky (taps flipped first when `flip`).
+__device__ __forceinline__ void pack_halo_wino_body(const float* src, int A, int B, long sa, long sb, long st, __bf16* dst,
+                                                    int nchunk, int ntile, int flip, const float* wamax, int nchunk_total,
+                                                    int ch_off, int WN) {
+  const float sc = wamax ? pow2_scale(*wamax) : 1.f;
+  const long total = (long)12 * nchunk * ntile * WN * 2 * 64 * 8;      // elements per plane
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), ks = (int)((e >> 9) & 1);
+    long r = e >> 10;
+    const int wv = (int)(r % WN); r /= WN;
+    const int nt = (int)(r % ntile); r /= ntile;
+    const int ch = (int)(r % nchunk);
+    const int t = (int)(r / nchunk);
+    const int ky = t >> 2, xi = t & 3;
+    const int a = (nt * WN + wv) * 32 + (lane & 31), b = ch * 32 + ks * 16 + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (a < A && b < B) {
+      const float* g = src + a * sa + b * sb;
+      float g0 = g[(flip ? 8 - (ky * 3 + 0) : ky * 3 + 0) * st];
+      float g1 = g[(flip ? 8 - (ky * 3 + 1) : ky * 3 + 1) * st];
+      float g2 = g[(flip ? 8 - (ky * 3 + 2) : ky * 3 + 2) * st];
+      v = xi == 0 ? g0 : (xi == 3 ? g2 : (xi == 1 ? 0.5f * ((g0 + g2) + g1) : 0.5f * ((g0 + g2) - g1)));
+    }
+    __bf16* o = dst + ((((((long)t * nchunk_total + ch_off + ch) * ntile + nt) * WN + wv) * 2 + ks) * 2) * 512 + lane * 8 + j;
+    if (wamax) {
+      v *= sc;
+      const _Float16 h = (_Float16)v;
+      o[0] = __builtin_bit_cast(__bf16, h);
+      o[512] = __builtin_bit_cast(__bf16, (_Float16)(v - (float)h));
+    } else {
+      const __bf16 h = (__bf16)v;
+      o[0] = h;
+      o[512] = (__bf16)(v - (float)h);
+    }
+  }
+}
 
 // packed weights for the generic split kernels: dst[plane][a][Kp] (see mt_weight_pack_split)
 __device__ __forceinline__ void pack_split_body(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,

@@ -168,32 +168,21 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
     }
   }
 
-  // ---- epilogue (same fused ops as igemm_epilogue, tile-local pixel map) ---
+  // ---- epilogue (tile-local pixel map; conv_common.h: halo_epilogue), one 32 x 32 tile at a time ----
   float vmax = 0.f;
 #pragma unroll
-  for (int a = 0; a < TM; ++a) {
+  for (int b = 0; b < TN; ++b) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;     // MFMA row -> tile pixel
-      const int i32 = row & 31;
-      const int oy = ty0 + (row >> 4), ox = tx0 + (i32 < 16 ? i32 : ((i32 - HW_) & 15));
-      if (oy >= p.Ho || ox >= p.Wo) continue;
-      const long yo = (long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + (long)oy * p.ysh + (long)ox * p.ysw;
-      const long ro = p.res ? (long)n * p.rsn + (long)oy * p.rsh + (long)ox * p.rsw : 0;
-      const long so = p.ds ? (long)n * p.dsn + (long)oy * p.dsh + (long)ox * p.dsw : 0;
+    for (int a = 0; a < TM; ++a) {
+      float vals[16];
 #pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int o = n0 + wn * TN * 32 + b * 32 + li;
-        if (o >= p.Co) continue;
-        float v = acc[a][b][r] * inv;
-        if (p.bias) v += p.bias[o];
-        v = mt_act_fn(v, p.act) * p.alpha;
-        if (p.res) v += p.beta * p.res[ro + o];
-        if (p.accumulate) v += p.y[yo + o];
-        if (p.ds && o >= p.dact_c0) v *= mt_dact_fn(p.ds[so + o], p.dact);
-        p.y[yo + o] = v;
-        vmax = fmaxf(vmax, fabsf(v));
-      }
+      for (int r = 0; r < 16; ++r) vals[r] = acc[a][b][r] * inv;
+      vmax = fmaxf(vmax, halo_epilogue<16>(p, n, n0 + wn * TN * 32 + b * 32 + li, vals, [&](int r, int& oy, int& ox) {
+        const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;     // MFMA row -> tile pixel
+        const int i32 = row & 31;
+        oy = ty0 + (row >> 4);
+        ox = tx0 + (i32 < 16 ? i32 : ((i32 - HW_) & 15));
+      }));
     }
   }
   if (p.yamax) raise_amax(p.yamax, vmax);
@@ -338,26 +327,15 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_rb_kernel(ConvK p, int tile
   float vmax = 0.f;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
+    float vals[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 16; ++r) vals[r] = acc[a][0][r] * inv;
+    vmax = fmaxf(vmax, halo_epilogue<16>(p, n, n0 + wn * 32 + li, vals, [&](int r, int& oy, int& ox) {
       const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       const int i32 = row & 31;
-      const int oy = ty0 + (row >> 4), ox = tx0 + (i32 < 16 ? i32 : ((i32 - HW_) & 15));
-      if (oy >= p.Ho || ox >= p.Wo) continue;
-      const long yo = (long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + (long)oy * p.ysh + (long)ox * p.ysw;
-      const long ro = p.res ? (long)n * p.rsn + (long)oy * p.rsh + (long)ox * p.rsw : 0;
-      const long so = p.ds ? (long)n * p.dsn + (long)oy * p.dsh + (long)ox * p.dsw : 0;
-      const int o = n0 + wn * 32 + li;
-      if (o >= p.Co) continue;
-      float v = acc[a][0][r] * inv;
-      if (p.bias) v += p.bias[o];
-      v = mt_act_fn(v, p.act) * p.alpha;
-      if (p.res) v += p.beta * p.res[ro + o];
-      if (p.accumulate) v += p.y[yo + o];
-      if (p.ds && o >= p.dact_c0) v *= mt_dact_fn(p.ds[so + o], p.dact);
-      p.y[yo + o] = v;
-      vmax = fmaxf(vmax, fabsf(v));
-    }
+      oy = ty0 + (row >> 4);
+      ox = tx0 + (i32 < 16 ? i32 : ((i32 - HW_) & 15));
+    }));
   }
   if (p.yamax) raise_amax(p.yamax, vmax);
 }
@@ -372,11 +350,22 @@ bool halo_rb_wanted(int cin_p, int cout_p) {
   return on && cin_p > 32 && cout_p > 32;
 }
 
+}  // namespace
+bool halo_wino_enabled();                                            // conv_halo_wino.hip
+void mt_halo_wino_launch(const void* convk, int fmt, void* stream);
+namespace {
+// 1-D Winograd F(2,3) on the 3 x 3 layers the register-B kernel would take (T = 9 taps)
+bool halo_wino_wanted(int cin_p, int cout_p, int T) { return T == 9 && halo_rb_wanted(cin_p, cout_p) && halo_wino_enabled(); }
+
 template <int KS, int NS, int FMT>
 void launch_halo(const ConvK& k, hipStream_t s) {
   const int tiles_y = (k.Ho + 7) / 8, tiles_x = (k.Wo + 15) / 16;
   const unsigned nt = (unsigned)k.N * tiles_y * tiles_x;
   if constexpr (NS == 2) {
+    if (halo_wino_wanted(k.C, k.Co, KS * KS)) {
+      mt_halo_wino_launch(&k, FMT, s);
+      return;
+    }
     if (halo_rb_wanted(k.C, k.Co)) {
       if (k.Co > 64)
         hipLaunchKernelGGL((igemm_halo_rb_kernel<KS, FMT, 1>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, tiles_y, tiles_x);
@@ -494,6 +483,11 @@ __device__ __forceinline__ void pack_halo_rb_body(const float* src, int A, int B
   }
 }
 
+__global__ void weight_pack_halo_wino_kernel(const float* src, int A, int B, long sa, long sb, long st, __bf16* dst, int nchunk,
+                                             int ntile, int flip, const float* wamax, int nchunk_total, int ch_off, int WN) {
+  pack_halo_wino_body(src, A, B, sa, sb, st, dst, nchunk, ntile, flip, wamax, nchunk_total, ch_off, WN);
+}
+
 __global__ void weight_pack_halo_rb_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
                                            int nchunk, int ntile, int flip, const float* wamax, int nchunk_total,
                                            int ch_off, int WN) {
@@ -514,7 +508,9 @@ __global__ void weight_pack_jobs_kernel(const mt_pack_job* jobs) {
   const int BN = j.AP > 64 ? 128 : (j.AP > 32 ? 64 : 32);
   const int nchunk = (j.BP + CK - 1) / CK, ntile = (j.AP + BN - 1) / BN;
   const int nchunk_total = (j.BP_total + CK - 1) / CK, ch_off = j.b_off / CK;
-  if (j.frag_order)
+  if (j.frag_order == 2)
+    pack_halo_wino_body(j.src, j.A, j.B, j.sa, j.sb, j.st, dst, nchunk, ntile, j.flip, j.w_amax, nchunk_total, ch_off, BN / 32);
+  else if (j.frag_order)
     pack_halo_rb_body(j.src, j.A, j.B, j.T, j.sa, j.sb, j.st, dst, nchunk, ntile, j.flip, j.w_amax, nchunk_total, ch_off,
                       BN / 32);
   else
@@ -534,6 +530,7 @@ __global__ void absmax_segments_kernel(const mt_amax_seg* segs) {
 extern "C" int64_t mt_weight_pack_halo_elems(int32_t AP, int32_t BP, int32_t T, int32_t precision) {
   const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = NS == 3 ? 16 : 32, LD = CK + 8;
   const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);
+  if (NS == 2 && halo_wino_wanted(BP, AP, T)) T = 12;      // the (ky, xi) "taps" of the Winograd image (fragment order)
   return (int64_t)T * ((BP + CK - 1) / CK) * ((AP + BN - 1) / BN) * NS * BN * LD;
 }
 
@@ -551,6 +548,13 @@ static int pack_halo_impl(const float* src, int32_t A, int32_t B, int32_t T, int
   const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);        // the n-tile igemm_halo uses for Co = AP
   const int nchunk = (BP + CK - 1) / CK, ntile = (AP + BN - 1) / BN;
   const int nchunk_total = (BP_total + CK - 1) / CK, ch_off = b_off / CK;
+  if (NS == 2 && halo_wino_wanted(BP_total, AP, T)) {     // Winograd-transformed fragments for igemm_halo_wino_kernel
+    const long tot = (long)12 * nchunk * ntile * (BN / 32) * 1024;
+    hipLaunchKernelGGL(weight_pack_halo_wino_kernel, dim3(mt_grid_1d(tot, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, A, B, (long)sa, (long)sb, (long)st,
+                       reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, w_amax, nchunk_total, ch_off, BN / 32);
+    return mt_check_launch("mt_weight_pack_halo(wino)");
+  }
   if (NS == 2 && halo_rb_wanted(BP_total, AP)) {     // fragment order for igemm_halo_rb_kernel (fits the same buffer)
     const long tot = (long)T * nchunk * ntile * (BN / 32) * 1024;
     hipLaunchKernelGGL(weight_pack_halo_rb_kernel, dim3(mt_grid_1d(tot, 256)), dim3(256), 0,
@@ -578,8 +582,9 @@ extern "C" int mt_weight_pack_halo_part(const float* src, int32_t A, int32_t B, 
   return pack_halo_impl(src, A, B, T, sa, sb, st, dst, AP, BP, precision, flip, w_amax, BP_total, b_off, stream);
 }
 
-extern "C" int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, int32_t precision) {
-  return (precision != MT_PREC_BF16X6 && halo_rb_wanted(BP_total, AP)) ? 1 : 0;
+extern "C" int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, int32_t T, int32_t precision) {
+  if (precision == MT_PREC_BF16X6 || !halo_rb_wanted(BP_total, AP)) return 0;
+  return halo_wino_wanted(BP_total, AP, T) ? 2 : 1;
 }
 
 extern "C" int mt_absmax_segments(const mt_amax_seg* segs_dev, int32_t nseg, void* stream) {
@@ -601,7 +606,7 @@ extern "C" int mt_weight_pack_jobs(const mt_pack_job* jobs_dev, const mt_pack_jo
     MT_REQUIRE((j.precision == MT_PREC_F16X3) == (j.w_amax != nullptr), "mt_weight_pack_jobs: job %d: w_amax goes with F16X3", i);
     if (j.kind == MT_PACK_HALO) {
       const int CK = j.precision == MT_PREC_BF16X6 ? 16 : 32;
-      MT_REQUIRE(j.frag_order == mt_weight_pack_halo_frag_order(j.AP, j.BP_total, j.precision),
+      MT_REQUIRE(j.frag_order == mt_weight_pack_halo_frag_order(j.AP, j.BP_total, j.T, j.precision),
                  "mt_weight_pack_jobs: job %d: frag_order must be mt_weight_pack_halo_frag_order()", i);
       MT_REQUIRE((j.BP & 7) == 0 && j.b_off >= 0 && j.b_off % CK == 0 && j.b_off + j.BP <= j.BP_total &&
                      (j.b_off + j.BP == j.BP_total || j.BP % CK == 0),

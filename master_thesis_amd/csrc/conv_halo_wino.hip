@@ -1,0 +1,394 @@
+// Stride-1 3x3 "same" convolutions with a 1-D Winograd F(2, 3) transform along W on top of the
+// register-B halo-tile kernel (conv_halo.hip): the layers that carry most of the DFPN / CHN FLOPs
+// (SeparableConv4d, FlowEstimator, VGG: model_dfpn.py:596-605,686-711, model_vgg.py:40-41, and with
+// tap-flipped, channel-swapped weights their backward-data).
+//
+//   y[oy][2t + j] = sum_ky  A^T ( (G g[ky][:]) .* (B^T x[oy + ky - 1][2t - 1 .. 2t + 2]) )
+//   B^T d = (d0 - d2, d1 + d2, d2 - d1, d1 - d3)     G g = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)
+//   A^T m = (m0 + m1 + m2, m1 - m2 - m3)
+//
+// Two output pixels cost 3 rows x 4 products instead of 3 x 3 x 2: 1.5x fewer MFMAs, with
+// transforms that only add (no amplification beyond 2x, so the split-fp16 operands keep their
+// per-tensor power-of-two scales).  The block owns 8 x 16 output pixels = 8 rows x 8 column pairs:
+// the GEMM's M index is (row, pair), its "taps" are the 12 (ky, xi) combinations, and the four
+// xi of a pair keep separate accumulators until the epilogue's output transform (in registers: all
+// four sit in the same lane).  Per 32-channel K chunk the (8 + 2) x 18 input halo is loaded once,
+// transformed and split into two 16-bit planes once, and written as the image
+//   V[plane][row 10][xi 4][pair 8][32 ch]      (64-byte entries, rows padded by 16 B)
+// whose ds_read_b128 fragment reads are bank-conflict free; weight fragments come straight from
+// global memory in MFMA operand order (mt_weight_pack_halo writes G g in that order).
+#include <cstdlib>
+#include "conv_common.h"
+
+namespace {
+
+template <int FMT, int WM>
+__global__ __launch_bounds__(256, 2) void igemm_halo_wino_kernel(ConvK p, int tiles_y, int tiles_x) {
+  constexpr int NS = 2, CK = 32, TH = 8, TW = 16, WN = 4 / WM, BN = WN * 32, TM = 2 / WM;
+  constexpr int NTX = TW / 2, ROWS = TH + 2;
+  constexpr int ENT = CK;                              // bf16 per entry (64 B)
+  constexpr int ROW_E = 4 * NTX * ENT + 8;             // bf16 per V row: 32 entries + 16 B pad
+  constexpr int PLANE_E = ROWS * ROW_E;
+  constexpr int NIT = ROWS * NTX * (CK / 4), RI = (NIT + 255) / 256;
+  constexpr int T = 12, KSTEPS = CK / 16;
+  __shared__ __attribute__((aligned(16))) __bf16 sV[NS * PLANE_E];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx_ = bid % tiles_x; bid /= tiles_x;
+  const int ty_ = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int ty0 = ty_ * TH, tx0 = tx_ * TW, n0 = blockIdx.y * BN;
+  const int HL = p.H << p.ups, WL = p.W << p.ups;
+  const float scA = FMT ? pow2_scale(*p.xamax) : 1.f;
+  const float inv = FMT ? 1.f / (scA * pow2_scale(*p.wamax)) : 1.f;
+  const float* xin = p.x + (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
+
+  // ---- transform items: (halo row r, column pair t, channel quad c4), c4 fastest --------------
+  // (32-bit element offsets inside one image; the four pixels of an item are re-derived per load)
+  int it_row[RI], it_lx[RI];
+  unsigned it_ok[RI];                                   // bit b: pixel b of the item lies inside the image
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int q = tid + 256 * i;
+    const int c4 = q & 7, t = (q >> 3) & 7, r = q >> 6;
+    const int ly = ty0 - 1 + r;
+    it_ok[i] = 0;
+    it_lx[i] = tx0 - 1 + 2 * t;
+    it_row[i] = (int)((long)(ly >> p.ups) * p.xsh) + 4 * c4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int lx = it_lx[i] + b;
+      const bool ok = q < NIT && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL;
+      it_ok[i] |= ok ? (1u << b) : 0u;
+    }
+  }
+  const int xsw = (int)p.xsw;
+  f32x4 rh[RI][4];
+  auto load_raw = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      const int c4 = (tid + 256 * i) & 7;
+      const bool cin = c0 + 4 * c4 < p.C;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (((it_ok[i] >> b) & 1u) && cin)
+          v = *reinterpret_cast<const f32x4*>(xin + (it_row[i] + ((it_lx[i] + b) >> p.ups) * xsw + c0));
+        rh[i][b] = v;
+      }
+    }
+  };
+  auto store_v = [&]() {
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      const int q = tid + 256 * i;
+      if (q < NIT) {
+        const int c4 = q & 7, t = (q >> 3) & 7, r = q >> 6;
+        const f32x4 d0 = rh[i][0], d1 = rh[i][1], d2 = rh[i][2], d3 = rh[i][3];
+        const f32x4 v[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+        __bf16* dst = sV + r * ROW_E + t * ENT + 4 * c4;
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+          bf16x4 parts[NS];
+          split4f<NS, FMT>(v[xi], scA, parts);
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+            *reinterpret_cast<bf16x4*>(dst + s * PLANE_E + xi * NTX * ENT) = parts[s];
+        }
+      }
+    }
+  };
+  // weight fragments: [tap 12][chunk][ntile][wn][kstep][plane][lane] x 16 B  (tap = ky * 4 + xi)
+  const bf16x8* wfr = reinterpret_cast<const bf16x8*>(p.wt);
+  const int nchunk = (p.C + CK - 1) / CK, ntile_w = (p.Co + BN - 1) / BN;
+  bf16x8 fb[KSTEPS][NS];
+  auto load_B = [&](int ch, int tap, int ks) {
+    const bf16x8* f = wfr + ((((long)tap * nchunk + ch) * ntile_w + blockIdx.y) * WN + wn) * (KSTEPS * NS * 64) +
+                      ks * NS * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) fb[ks][s] = f[s * 64];
+  };
+
+  f32x16 acc[TM][4];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][xi][r] = 0.f;
+
+  // MFMA row i of M tile a = (output row 4a + (i >> 3), column pair i & 7)
+  int a_base[TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) a_base[a] = (4 * (wm * TM + a) + (li >> 3)) * ROW_E + (li & 7) * ENT + 8 * lh;
+
+  load_raw(0);
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) load_B(0, 0, ks);
+  store_v();
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const bool more = ch + 1 < nchunk;
+    // fully unrolled: the accumulator of a tap (xi = tap & 3) must be a compile-time choice
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) {
+      const int ky = tap >> 2, xi = tap & 3;
+      const bool last = tap == T - 1;
+      const int toff = ky * ROW_E + xi * NTX * ENT;
+      bf16x8 fa[KSTEPS][TM][NS];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+            fa[ks][a][s] = *reinterpret_cast<const bf16x8*>(&sV[s * PLANE_E + a_base[a] + toff + ks * 16]);
+      __builtin_amdgcn_sched_barrier(0);     // (all fragment reads of the tap are requested ahead of its MFMAs)
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(fa[ks][a], fb[ks], acc[a][xi]);
+        if (!last) load_B(ch, tap + 1, ks);
+        else if (more) load_B(ch + 1, 0, ks);
+      }
+      if (tap == T - 4 && more) load_raw((ch + 1) * CK);     // in flight under the last taps
+    }
+    if (more) {
+      __syncthreads();            // every wave is done reading this chunk's image
+      store_v();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: output transform (in registers) + the fused ops ------------------------------
+  const int o = n0 + wn * 32 + li;
+  const int oyb = ty0 + 4 * wm * TM, oxb = tx0 + 8 * lh;
+  float vmax = 0.f;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {            // (16 values at a time: this kernel has no registers to spare)
+      float vals[16];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = 8 * h + q;
+        const float m0 = acc[a][0][r], m1 = acc[a][1][r], m2 = acc[a][2][r], m3 = acc[a][3][r];
+        vals[q * 2] = (m0 + m1 + m2) * inv;
+        vals[q * 2 + 1] = (m1 - m2 - m3) * inv;
+      }
+      vmax = fmaxf(vmax, halo_epilogue<16>(p, n, o, vals, [&](int e, int& oy, int& ox) {
+        const int r = 8 * h + (e >> 1), j = e & 1;
+        oy = oyb + 4 * a + (r >> 2);
+        ox = oxb + 2 * (r & 3) + j;
+      }));
+    }
+  }
+  if (p.yamax) raise_amax(p.yamax, vmax);
+}
+
+// ---- 16 x 16-pixel tiles, 8 waves, double-buffered image ------------------------------------
+// The 8 x 16 kernel above leaves a wave 12 MFMAs per tap (four accumulator sets cost it half of the
+// direct kernel's pixel tile), which is too little to cover the latency of its weight fragments
+// (an L2 hit) and of the next chunk's halo -- measured: without those two loads it runs 30 % faster.
+// This variant keeps the per-wave tile and spends the CU differently: ONE 512-thread block per CU
+// owns 16 x 16 output pixels x 128 channels (waves = 2 row halves x 4 channel quarters, 2 waves per
+// SIMD), the transformed image of the (16 + 2) x 18 halo is double-buffered (all 148 KB of it), so
+//   * the next chunk's halo is loaded, transformed and written in three rounds spread over the 12
+//     taps of the current chunk (one 16-register round in flight), with ONE barrier per chunk;
+//   * weight fragments are fetched two taps ahead (two register sets);
+//   * the two row-half waves of a channel quarter read the same fragments (the second hits L1).
+template <int FMT>
+__global__ __launch_bounds__(512, 2) void igemm_wino16_kernel(ConvK p, int tiles_y, int tiles_x) {
+  constexpr int NS = 2, CK = 32, TH = 16, TW = 16, BN = 128, TM = 2;
+  constexpr int NTX = TW / 2, ROWS = TH + 2;
+  constexpr int ENT = CK, ROW_E = 4 * NTX * ENT + 8, PLANE_E = ROWS * ROW_E, BUF_E = NS * PLANE_E;
+  constexpr int NIT = ROWS * NTX * (CK / 4), RI = (NIT + 511) / 512;      // 1152 items, 3 rounds
+  constexpr int T = 12, KSTEPS = CK / 16;
+  static_assert(RI == 3, "three transform rounds per chunk");
+  __shared__ __attribute__((aligned(16))) __bf16 sV[2 * BUF_E];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm2 = wave >> 2, wn = wave & 3;
+  const int li = lane & 31, lh = lane >> 5;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx_ = bid % tiles_x; bid /= tiles_x;
+  const int ty_ = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int ty0 = ty_ * TH, tx0 = tx_ * TW, n0 = blockIdx.y * BN;
+  const int HL = p.H << p.ups, WL = p.W << p.ups;
+  const float scA = FMT ? pow2_scale(*p.xamax) : 1.f;
+  const float inv = FMT ? 1.f / (scA * pow2_scale(*p.wamax)) : 1.f;
+  const float* xin = p.x + (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
+  const int xsw = (int)p.xsw;
+
+  // transform items (halo row r, column pair t, channel quad c4), c4 fastest; round i owns q = tid + 512 i
+  int it_row[RI], it_lx[RI], it_dst[RI];
+  unsigned it_ok[RI];
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int q = tid + 512 * i;
+    const int c4 = q & 7, t = (q >> 3) & 7, r = q >> 6;
+    const int ly = ty0 - 1 + r;
+    it_ok[i] = 0;
+    it_lx[i] = tx0 - 1 + 2 * t;
+    it_row[i] = (int)((long)(ly >> p.ups) * p.xsh) + 4 * c4;
+    it_dst[i] = r * ROW_E + t * ENT + 4 * c4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int lx = it_lx[i] + b;
+      const bool ok = q < NIT && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL;
+      it_ok[i] |= ok ? (1u << b) : 0u;
+    }
+    if (q < NIT) it_ok[i] |= 16u;                       // bit 4: the item exists
+  }
+  auto load_item = [&](f32x4 (&d)[4], int i, int c0) {
+    const int c4 = (tid + 512 * i) & 7;
+    const bool cin = c0 + 4 * c4 < p.C;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (((it_ok[i] >> b) & 1u) && cin)
+        v = *reinterpret_cast<const f32x4*>(xin + (it_row[i] + ((it_lx[i] + b) >> p.ups) * xsw + c0));
+      d[b] = v;
+    }
+  };
+  auto store_item = [&](const f32x4 (&d)[4], int i, int buf) {
+    if (it_ok[i] & 16u) {
+      const f32x4 v[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
+      __bf16* dst = sV + buf * BUF_E + it_dst[i];
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        bf16x4 parts[NS];
+        split4f<NS, FMT>(v[xi], scA, parts);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          *reinterpret_cast<bf16x4*>(dst + s * PLANE_E + xi * NTX * ENT) = parts[s];
+      }
+    }
+  };
+  // weight fragments: [tap 12][chunk][ntile][wn 4][kstep][plane][lane] x 16 B
+  const bf16x8* wfr = reinterpret_cast<const bf16x8*>(p.wt);
+  const int nchunk = (p.C + CK - 1) / CK, ntile_w = (p.Co + BN - 1) / BN;
+  bf16x8 fb[2][KSTEPS][NS];
+  auto load_B = [&](bf16x8 (&f)[NS], int ch, int tap, int ks) {
+    const bf16x8* g = wfr + ((((long)tap * nchunk + ch) * ntile_w + blockIdx.y) * 4 + wn) * (KSTEPS * NS * 64) +
+                      ks * NS * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) f[s] = g[s * 64];
+  };
+
+  // ---- prologue: the whole first image (the accumulators are not live yet) ---------------------
+  {
+    f32x4 r0[4], r1[4], r2[4];
+    load_item(r0, 0, 0);
+    load_item(r1, 1, 0);
+    load_item(r2, 2, 0);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) { load_B(fb[0][ks], 0, 0, ks); load_B(fb[1][ks], 0, 1, ks); }
+    store_item(r0, 0, 0);
+    store_item(r1, 1, 0);
+    store_item(r2, 2, 0);
+  }
+  f32x16 acc[TM][4];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][xi][r] = 0.f;
+  int a_base[TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) a_base[a] = (8 * wm2 + 4 * a + (li >> 3)) * ROW_E + (li & 7) * ENT + 8 * lh;
+  __syncthreads();
+
+  f32x4 rh[4];
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const bool more = ch + 1 < nchunk;
+    const __bf16* vb = sV + (ch & 1) * BUF_E;
+    const int nb = (ch & 1) ^ 1;
+#pragma unroll
+    for (int tap = 0; tap < T; ++tap) {
+      const int ky = tap >> 2, xi = tap & 3;
+      const int toff = ky * ROW_E + xi * NTX * ENT;
+      // the next chunk's image: round i is loaded at tap 4 i and transformed + written at tap 4 i + 3
+      if ((tap & 3) == 0 && more) load_item(rh, tap >> 2, (ch + 1) * CK);
+      bf16x8 fa[KSTEPS][TM][NS];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+            fa[ks][a][s] = *reinterpret_cast<const bf16x8*>(&vb[s * PLANE_E + a_base[a] + toff + ks * 16]);
+      __builtin_amdgcn_sched_barrier(0);     // (all fragment reads of the tap are requested ahead of its MFMAs)
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(fa[ks][a], fb[tap & 1][ks], acc[a][xi]);
+        // this slot's next contents: the same k-step two taps on
+        if (tap + 2 < T) load_B(fb[tap & 1][ks], ch, tap + 2, ks);
+        else if (more) load_B(fb[tap & 1][ks], ch + 1, tap + 2 - T, ks);
+      }
+      if ((tap & 3) == 3 && more) store_item(rh, tap >> 2, nb);
+    }
+    if (more) __syncthreads();      // the other image is complete, nobody reads this one any more
+  }
+
+  // ---- epilogue: output transform (in registers) + the fused ops, one M tile at a time --------
+  const int o = n0 + wn * 32 + li;
+  const int oyb = ty0 + 8 * wm2, oxb = tx0 + 8 * lh;
+  float vmax = 0.f;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    float vals[32];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[a][0][r], m1 = acc[a][1][r], m2 = acc[a][2][r], m3 = acc[a][3][r];
+      vals[r * 2] = (m0 + m1 + m2) * inv;
+      vals[r * 2 + 1] = (m1 - m2 - m3) * inv;
+    }
+    // element (r, j): C/D row (r & 3) + 8 (r >> 2) + 4 lh -> output row r >> 2 of M tile a, column pair (r & 3) + 4 lh
+    vmax = fmaxf(vmax, halo_epilogue<32>(p, n, o, vals, [&](int e, int& oy, int& ox) {
+      const int r = e >> 1, j = e & 1;
+      oy = oyb + 4 * a + (r >> 2);
+      ox = oxb + 2 * (r & 3) + j;
+    }));
+  }
+  if (p.yamax) raise_amax(p.yamax, vmax);
+}
+
+}  // namespace
+
+// MT355_WINO=0 keeps the direct register-B kernel on every layer (A/B switch).
+bool halo_wino_enabled() {
+  static const bool on = [] { const char* e = getenv("MT355_WINO"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+// Launch for a layer launch_halo<3, 2, FMT> sends to the register-B path (C > 32, Co > 32).
+void mt_halo_wino_launch(const void* kp, int fmt, void* stream) {
+  const ConvK& k = *static_cast<const ConvK*>(kp);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int tiles_y = (k.Ho + 7) / 8, tiles_x = (k.Wo + 15) / 16;
+  const unsigned nt = (unsigned)k.N * tiles_y * tiles_x;
+  static const bool big = [] { const char* e = getenv("MT355_WINO16"); return !(e && e[0] == '0'); }();
+  if (k.Co > 64 && big && k.Ho > 8) {          // 16 x 16 tiles (an 8-row image would waste half of one)
+    const int ty16 = (k.Ho + 15) / 16;
+    const unsigned nt16 = (unsigned)k.N * ty16 * tiles_x;
+    if (fmt) hipLaunchKernelGGL((igemm_wino16_kernel<1>), dim3(nt16, (k.Co + 127) / 128), dim3(512), 0, s, k, ty16, tiles_x);
+    else hipLaunchKernelGGL((igemm_wino16_kernel<0>), dim3(nt16, (k.Co + 127) / 128), dim3(512), 0, s, k, ty16, tiles_x);
+    return;
+  }
+  if (k.Co > 64) {
+    if (fmt) hipLaunchKernelGGL((igemm_halo_wino_kernel<1, 1>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, tiles_y, tiles_x);
+    else hipLaunchKernelGGL((igemm_halo_wino_kernel<0, 1>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, tiles_y, tiles_x);
+  } else {
+    if (fmt) hipLaunchKernelGGL((igemm_halo_wino_kernel<1, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+    else hipLaunchKernelGGL((igemm_halo_wino_kernel<0, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+  }
+}

@@ -87,17 +87,23 @@ def halo_eligible(kind_fwd_like, stride, k, cin_p):
 
 
 HALO_RB = os.environ.get('MT355_HALO_RB', '1') != '0'     # mirrors halo_rb_wanted() in conv_halo.hip
+HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_enabled() in conv_halo_wino.hip
 
 
 def _igemm_name(co, halo, prec, cin_p=0):
     """Name of the kernel mt_conv_run picks (profiling labels only)."""
     cfg = '2,2,2,2' if co > 64 else ('2,2,2,1' if co > 32 else '4,1,1,1')
     if halo and prec in ('f16x3', 'bf16x3') and cin_p > 32 and co > 32 and HALO_RB:
-        return 'igemm_halo_rb_kernel<{k},%s,%d>' % ('f16' if prec == 'f16x3' else 'bf16', 1 if co > 64 else 2)
+        # ('{k}' == 3: the 1-D Winograd F(2,3) variant; the caller substitutes k)
+        return 'igemm_halo_{rbw}_kernel<{k},%s,%d>' % ('f16' if prec == 'f16x3' else 'bf16', 1 if co > 64 else 2)
     if halo:
         return 'igemm_halo_kernel<{k},%s,%s>' % (_HTAG[prec], cfg)
     base = 'igemm_kernel' if prec == 'f32' else 'igemm_split_kernel'
     return f'{base}<{cfg}{_KTAG[prec]}>'
+
+
+def _kname(template, k):
+    return template.replace('{rbw}', 'wino' if (k == 3 and HALO_WINO) else 'rb').replace('{k}', str(k))
 
 
 class _Prof:
@@ -278,7 +284,7 @@ def stack_amax(weights):
 
 def _job(src_ptr, a, b, t, sa, sb, st, dst, ap, bp, prec, flip, wa, kind, bp_total=None, b_off=0):
     bp_total = bp if bp_total is None else bp_total
-    fo = L.load().mt_weight_pack_halo_frag_order(ap, bp_total, _PREC[prec]) if kind == 1 else 0
+    fo = L.load().mt_weight_pack_halo_frag_order(ap, bp_total, t, _PREC[prec]) if kind == 1 else 0
     return L.PackJob(src_ptr, dst.data_ptr(), wa.data_ptr() if wa is not None else None, sa, sb, st, a, b, t, ap, bp,
                      _PREC[prec], 1 if flip else 0, kind, bp_total, b_off, fo)
 
@@ -512,7 +518,7 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
         flops = 2.0 * n * ho * wo * spec.cin * spec.cout * spec.k * spec.k
     else:
         flops = 2.0 * n * h * w_ * spec.cin * spec.cout * spec.k * spec.k
-    with _Prof(_igemm_name(d.y.C, halo, prec, xv.C).replace('{k}', str(spec.k)), flops):
+    with _Prof(_kname(_igemm_name(d.y.C, halo, prec, xv.C), spec.k), flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
     return out
 
@@ -553,7 +559,7 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     d.y_amax, keep_y = _out_amax(prec, y_amax, yv._src)
     side = d.x if spec.kind == 'c' else yv          # the conv's output side
     flops = 2.0 * side.N * side.H * side.W * spec.cin * spec.cout * spec.k * spec.k
-    with _Prof(_igemm_name(yv.C, as_fwd, prec, dzv.C).replace('{k}', str(spec.k)), flops):
+    with _Prof(_kname(_igemm_name(yv.C, as_fwd, prec, dzv.C), spec.k), flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
 
 

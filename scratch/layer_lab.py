@@ -1,0 +1,22 @@
+"""Lab: forward time of representative layers (env MT355_WINO etc. set by the caller)."""
+import sys, os
+sys.path.insert(0, '.')
+import torch
+from master_thesis_amd import engine as E
+dev = 'cuda:0'
+def bench(n, h, w, cin, cout, k, reps=10):
+    spec = E.LayerSpec('c', cin, cout, k, 1, 1)
+    x = torch.randn((n, h, w, E.cpad(cin)), device=dev); wt = torch.randn((cout, cin, k, k), device=dev) * 0.05
+    b = torch.zeros((cout,), device=dev)
+    run = lambda: E.conv_forward(spec, E.view_of(x), x.shape[:3], wt, b)
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f'{os.environ.get("TAG","")} N{n} {h}x{w} {cin}->{cout} k{k}: {ms:.3f} ms {2.0*n*h*w*cin*cout*k*k/ms/1e9:.0f} TF', flush=True)
+for sh in [(32, 256, 256, 128, 128, 3), (8192, 16, 16, 256, 256, 3), (32, 128, 128, 128, 128, 3), (32, 256, 256, 128, 128, 5),
+           (32, 64, 64, 160, 32, 3), (32, 64, 64, 192, 64, 3), (32, 256, 256, 10, 128, 5), (32, 256, 256, 128, 2, 3), (40, 256, 256, 64, 64, 3)]:
+    bench(*sh)

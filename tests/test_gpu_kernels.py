@@ -135,6 +135,33 @@ def test_conv_forward_backward(mt, case, precision):
         assert_close(out2, y4, tol=1e-5, what='naive vs mfma')
 
 
+@pytest.mark.parametrize('case', [(2, 32, 32, 128, 128), (1, 24, 40, 64, 64), (2, 16, 16, 256, 256), (1, 19, 27, 128, 256)])
+def test_conv3x3_f16x3_is_fp32_grade(mt, case):
+    """The default arithmetic on the hot 3 x 3 stride-1 layers (split fp16 operands, and on the
+    register-B shapes the 1-D Winograd F(2,3) transform) against an fp64 convolution: forward
+    and backward-data stay at fp32 rounding level, far inside the 1e-3 bar."""
+    from master_thesis_amd import engine as E
+    n, h, w, cin, cout = case
+    tag = 'c3p.' + '.'.join(map(str, case))
+    x = S.uniform(tag + '.x', (n, cin, h, w), -1, 1)
+    wt = S.uniform(tag + '.w', (cout, cin, 3, 3), -0.1, 0.1)
+    bs = S.uniform(tag + '.b', (cout,), -0.5, 0.5)
+    gy = S.uniform(tag + '.gy', (n, cout, h, w), -1, 1)
+    x64 = x.double().requires_grad_(True)
+    y64 = F.conv2d(x64, wt.double(), bs.double(), padding=1)
+    y64.backward(gy.double())
+    y32 = F.conv2d(x, wt, bs, padding=1)                                   # torch's own fp32 error, for scale
+    with E.precision('f16x3'):
+        xg = x.to(dev()).requires_grad_(True)
+        y4 = E.conv_stack(E.ToNHWC4Fn.apply(xg), [E.LayerSpec('c', cin, cout, 3, 1, 0)], [wt.to(dev()), bs.to(dev())])
+        y = E.FromNHWC4Fn.apply(y4, cout)
+        y.backward(gy.to(dev()))
+    e_fwd = float((y.detach().cpu().double() - y64.detach()).abs().max() / y64.detach().abs().max())
+    e_bwd = float((xg.grad.cpu().double() - x64.grad).abs().max() / x64.grad.abs().max())
+    e_ref = float((y32.double() - y64.detach()).abs().max() / y64.detach().abs().max())
+    assert e_fwd < 3e-6 and e_bwd < 3e-6, (e_fwd, e_bwd, e_ref)
+
+
 def test_conv_stack_chain(mt, precision):
     """A 3-layer chain with fused ReLU gating in the backward."""
     from master_thesis_amd import engine as E
