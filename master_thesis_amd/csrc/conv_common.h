@@ -178,6 +178,32 @@ __device__ __forceinline__ float halo_epilogue(const ConvK& p, int n, int o, flo
   return halo_epilogue_body<true, NE>(p, n, o, v, pix, okm);
 }
 
+// The same epilogue, one element at a time (no batches: few live registers).  For the small-tile
+// kernels, which are latency bound and live on occupancy (104 VGPRs = 4 blocks per CU).
+template <int NE, class PixFn>
+__device__ __forceinline__ float halo_epilogue_lean(const ConvK& p, int n, int o, float (&v)[NE], PixFn pix) {
+  if (o >= p.Co) return 0.f;
+  const float bv = p.bias ? p.bias[o] : 0.f;
+  float* yb = p.y + ((long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + o);
+  const float* rb = p.res ? p.res + ((long)n * p.rsn + o) : nullptr;
+  const float* db = (p.ds && o >= p.dact_c0) ? p.ds + ((long)n * p.dsn + o) : nullptr;
+  const int ysh = (int)p.ysh, ysw = (int)p.ysw, rsh = (int)p.rsh, rsw = (int)p.rsw, dsh = (int)p.dsh, dsw = (int)p.dsw;
+  float vmax = 0.f;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    int oy, ox;
+    pix(e, oy, ox);
+    if (oy >= p.Ho || ox >= p.Wo) continue;
+    float x = mt_act_fn(v[e] + bv, p.act) * p.alpha;
+    if (rb) x += p.beta * rb[oy * rsh + ox * rsw];
+    if (p.accumulate) x += yb[oy * ysh + ox * ysw];
+    if (db) x *= mt_dact_fn(db[oy * dsh + ox * dsw], p.dact);
+    yb[oy * ysh + ox * ysw] = x;
+    vmax = fmaxf(vmax, fabsf(x));
+  }
+  return vmax;
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));

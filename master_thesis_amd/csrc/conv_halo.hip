@@ -177,12 +177,15 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
       float vals[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) vals[r] = acc[a][b][r] * inv;
-      vmax = fmaxf(vmax, halo_epilogue<16>(p, n, n0 + wn * TN * 32 + b * 32 + li, vals, [&](int r, int& oy, int& ox) {
+      auto pix = [&](int r, int& oy, int& ox) {
         const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;     // MFMA row -> tile pixel
         const int i32 = row & 31;
         oy = ty0 + (row >> 4);
         ox = tx0 + (i32 < 16 ? i32 : ((i32 - HW_) & 15));
-      }));
+      };
+      // one / two accumulator tiles per wave: latency-bound variants that live on occupancy
+      if constexpr (TM * TN <= 2) vmax = fmaxf(vmax, halo_epilogue_lean<16>(p, n, n0 + wn * TN * 32 + b * 32 + li, vals, pix));
+      else vmax = fmaxf(vmax, halo_epilogue<16>(p, n, n0 + wn * TN * 32 + b * 32 + li, vals, pix));
     }
   }
   if (p.yamax) raise_amax(p.yamax, vmax);
