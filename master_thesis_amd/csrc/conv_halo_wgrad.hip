@@ -184,9 +184,180 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
   }
 }
 
+
+// ---- producer / consumer variant (stride 1, two-term splits) ---------------------------------
+// The kernel above runs ONE wave per SIMD (its nine accumulator tiles need the registers), so the
+// split + LDS store of every pixel tile sits between two barriers with the matrix pipe idle, and
+// the tile's first fragment reads wait on the second barrier (measured: pipe 42 % busy).  Here a
+// 512-thread block has two roles: waves 0-3 (one per SIMD) only issue MFMAs on the image in LDS
+// buffer i & 1, waves 4-7 (their SIMD partners) load, split and store the NEXT pixel tile into the
+// other buffer -- VALU / LDS-write work that runs in the shadow of the partner's MFMAs.  One
+// barrier per pixel tile; 4 x 16-pixel tiles so that two images fit in LDS (2 x 49.5 KB, 3 x 3).
+template <int KS, int KHB, int FMT>
+__global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split, int ntiles,
+                                                         int with_bias, int kh_base) {
+  constexpr int NS = 2, TR = 4, TW = 16, PX = TR * TW, CH = 64, LD = CH + 8;
+  constexpr int GH = TR - 1 + KHB, GW = TW - 1 + KS, GP = GH * GW;
+  constexpr int ND4 = PX * (CH / 4), RD = ND4 / 256;
+  constexpr int NG4 = GP * (CH / 4), RG = (NG4 + 255) / 256;
+  constexpr int NT = KHB * KS;
+  constexpr int D_E = NS * PX * LD, G_E = NS * GP * LD, BUF_E = D_E + G_E;
+  __shared__ __attribute__((aligned(16))) __bf16 sm[2 * BUF_E];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  int bid = blockIdx.x;
+  const int bt = bid % p.btiles; bid /= p.btiles;
+  const int at = bid % p.atiles; bid /= p.atiles;
+  const int kh0 = kh_base + bid * KHB;
+  if (at * p.btiles + bt < 32 && ((p.skip >> (at * p.btiles + bt)) & 1u)) return;   // tile nobody reads
+  const int a0 = at * CH, b0 = bt * CH;
+  const int split = blockIdx.y;
+  const int t_beg = split * tiles_per_split, t_end = min(ntiles, t_beg + tiles_per_split);
+  const int HL = p.Hg << p.ups, WL = p.Wg << p.ups;
+  const float scD = FMT ? pow2_scale(*p.damax) : 1.f, scG = FMT ? pow2_scale(*p.gamax) : 1.f;
+  const float inv = 1.f / (scD * scG), inv_d = 1.f / scD;
+
+  if (producer) {
+    // ---- waves 4-7: global -> registers -> split -> LDS, one tile ahead of the consumers --------
+    const int ptid = tid - 256;
+    f32x4 rd[RD], rg[RG];
+    auto load_tile = [&](int t) {
+      const int tx = t % tiles_x, r = t / tiles_x, ty = r % tiles_y, n = r / tiles_y;
+      const int ty0 = ty * TR, tx0 = tx * TW;
+      const float* dp = p.d + (long)(n / p.dni) * p.dsg + (long)(n % p.dni) * p.dsn;
+      const float* gp = p.g + (long)(n / p.gni) * p.gsg + (long)(n % p.gni) * p.gsn;
+#pragma unroll
+      for (int i = 0; i < RD; ++i) {
+        const int idx = ptid + 256 * i, px = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
+        const int y = ty0 + (px >> 4), x = tx0 + (px & 15);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y < p.Hd && x < p.Wd && a0 + c < p.Cd)
+          v = *reinterpret_cast<const f32x4*>(dp + (long)y * p.dsh + (long)x * p.dsw + a0 + c);
+        rd[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < RG; ++i) {
+        const int idx = ptid + 256 * i, gpx = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
+        const int gy = gpx / GW, gx = gpx - gy * GW;
+        const int ly = ty0 + gy + kh0 - p.pad, lx = tx0 + gx - p.pad;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (idx < NG4 && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL && b0 + c < p.Cg)
+          v = *reinterpret_cast<const f32x4*>(gp + (long)(ly >> p.ups) * p.gsh + (long)(lx >> p.ups) * p.gsw + b0 + c);
+        rg[i] = v;
+      }
+    };
+    auto store_tile = [&](int buf) {
+      __bf16* sD = sm + buf * BUF_E;
+      __bf16* sG = sD + D_E;
+#pragma unroll
+      for (int i = 0; i < RD; ++i) {
+        const int idx = ptid + 256 * i, px = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
+        bf16x4 parts[NS];
+        split4f<NS, FMT>(rd[i], scD, parts);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sD[s * PX * LD + px * LD + c]) = parts[s];
+      }
+#pragma unroll
+      for (int i = 0; i < RG; ++i) {
+        const int idx = ptid + 256 * i, gpx = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
+        if (idx < NG4) {
+          bf16x4 parts[NS];
+          split4f<NS, FMT>(rg[i], scG, parts);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sG[s * GP * LD + gpx * LD + c]) = parts[s];
+        }
+      }
+    };
+    if (t_beg < t_end) { load_tile(t_beg); store_tile(0); }
+    if (t_beg + 1 < t_end) load_tile(t_beg + 1);
+    __syncthreads();
+    for (int t = t_beg; t < t_end; ++t) {
+      if (t + 1 < t_end) store_tile((t + 1 - t_beg) & 1);
+      if (t + 2 < t_end) load_tile(t + 2);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---- waves 0-3: MFMAs only ------------------------------------------------------------------
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const bool do_bias = with_bias && bt == 0 && kh0 == 0;
+  f32x16 acc_bias;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_bias[r] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = FMT ? __builtin_bit_cast(__bf16, (_Float16)1.0f) : (__bf16)1.0f;
+  const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, g1 = (lane >> 4) & 1, lh = lane >> 5;
+  const int a_off = (8 * lh + q) * LD + wm * 32 + 16 * g1 + 4 * pp;
+  const int b_off = (8 * lh + q) * LD + wn * 32 + 16 * g1 + 4 * pp;
+
+  __syncthreads();
+  for (int t = t_beg; t < t_end; ++t) {
+    const __bf16* sD = sm + ((t - t_beg) & 1) * BUF_E;
+    const __bf16* sG = sD + D_E;
+#pragma unroll
+    for (int ks = 0; ks < TR; ++ks) {
+      bf16x8 fa[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) fa[s] = tr_frag(sD + s * PX * LD, a_off + ks * 16 * LD, LD);
+      if (do_bias) {
+#pragma unroll
+        for (int s = NS - 1; s >= 0; --s) {
+          if constexpr (FMT == 0) acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], ones, acc_bias, 0, 0, 0);
+          else acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[s]), __builtin_bit_cast(half8, ones), acc_bias, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int kh = 0; kh < KHB; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+          bf16x8 fb[NS];
+#pragma unroll
+          for (int s = 0; s < NS; ++s) fb[s] = tr_frag(sG + s * GP * LD, b_off + ((ks + kh) * GW + kw) * LD, LD);
+          mfma_splitf<NS, FMT>(fa, fb, acc[kh * KS + kw]);
+        }
+    }
+    __syncthreads();
+  }
+
+  const int T = p.KH * p.KW, li = lane & 31;
+  const int TS = T + (with_bias ? 1 : 0);
+  float* slab = p.slabs + (long)split * p.Cd * TS * p.Cg;
+  if (do_bias && wn == 0 && li == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ai < p.Cd) slab[((long)ai * TS + T) * p.Cg] = acc_bias[r] * inv_d;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tap = (kh0 + t / KS) * KS + (t % KS);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int bi = b0 + wn * 32 + li;
+      if (ai < p.Cd && bi < p.Cg) slab[((long)ai * TS + tap) * p.Cg + bi] = acc[t][r] * inv;
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
+// MT355_WGRAD_PC=0: stride-1 weight gradients stay on the single-role kernel (A/B switch)
+bool wgrad_pc() {
+  static const bool on = [] { const char* e = getenv("MT355_WGRAD_PC"); return !(e && e[0] == '0'); }();
+  return on;
+}
 // MT355_WGRAD5_ROWS=1 restores one kernel row per block for the 5x5 weight gradient (A/B switch)
 // MT355_WGRAD_S2_HALO=0: stride-2 weight gradients stay on the generic kernel (A/B switch)
 bool wgrad_s2_halo() {
@@ -222,8 +393,10 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   k.slabs = d->slabs;
   k.damax = d->d_amax; k.gamax = d->g_amax;
   k.skip = d->skip_tiles;
+  // stride 1, two-term splits: the producer / consumer kernel (4-row tiles, two LDS images)
+  const bool pc = d->stride == 1 && prec != MT_PREC_BF16X6 && wgrad_pc() && d->KH == 3;   // (5 x 5: three launches lose to 3 + 2 rows)
   // 3x3 stride 1 (two-term splits): 8-row pixel tiles (measured: +6 %; the 5x5 gradient loses 3 % with them) (twice the MFMAs per staged tile and barrier)
-  const bool tall = d->stride == 1 && d->KH == 3 && prec != MT_PREC_BF16X6 && wgrad3_tall();
+  const bool tall = !pc && d->stride == 1 && d->KH == 3 && prec != MT_PREC_BF16X6 && wgrad3_tall();
   const int trows = tall ? 8 : 4;
   const int tiles_y = (k.Hd + trows - 1) / trows, tiles_x = (k.Wd + 15) / 16;
   const int ntiles = d->d.N * tiles_y * tiles_x;
@@ -233,6 +406,18 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, NS, FMT, OCC>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
 #define MT_WGH2(KS, KHB, FMT, GRID, KH_BASE) \
   hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
+#define MT_WGPC(KS, KHB, FMT, KH_BASE) \
+  hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
+  if (pc) {
+    const bool f16 = prec == MT_PREC_F16X3;
+    if (d->KH == 3) { if (f16) MT_WGPC(3, 3, 1, 0); else MT_WGPC(3, 3, 0, 0); }
+    // 5 x 5: kernel rows {0,1} | {2,3} | {4} (15 accumulator tiles would not leave the MFMA waves
+    // their operand registers at two waves per SIMD; the staging is off the critical path here)
+    else if (f16) { MT_WGPC(5, 2, 1, 0); MT_WGPC(5, 2, 1, 2); MT_WGPC(5, 1, 1, 4); }
+    else { MT_WGPC(5, 2, 0, 0); MT_WGPC(5, 2, 0, 2); MT_WGPC(5, 1, 0, 4); }
+    return 1;
+  }
+#undef MT_WGPC
   if (d->stride == 2) {      // stride-2 gather: all 9 taps, or kernel rows {0,1,2} | {3,4}
     dim3 grid(k.atiles * k.btiles, d->splits);
     const bool f16 = prec == MT_PREC_F16X3;

@@ -87,6 +87,8 @@ def halo_eligible(kind_fwd_like, stride, k, cin_p):
 
 
 HALO_RB = os.environ.get('MT355_HALO_RB', '1') != '0'     # mirrors halo_rb_wanted() in conv_halo.hip
+WGRAD_PC = os.environ.get('MT355_WGRAD_PC', '1') != '0'   # mirrors wgrad_pc() in conv_halo_wgrad.hip
+WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '512'))
 HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_enabled() in conv_halo_wino.hip
 
 
@@ -629,11 +631,14 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
         # MT355_WGRAD5_ROWS=1: five one-row blocks) -- mirrors mt_wgrad_halo_try_launch
         rows5 = prec == 'bf16x6' or os.environ.get('MT355_WGRAD5_ROWS', '0') == '1'
         blocks = ((ap + 63) // 64) * ((bp + 63) // 64) * (1 if spec.k == 3 else (5 if rows5 else 2))
-        # pixel tiles of 8 x 16 for the 3x3 stride-1 gradient, 4 x 16 otherwise (as mt_wgrad_halo_try_launch)
-        trows = 8 if (spec.k == 3 and spec.stride == 1 and prec != 'bf16x6'
+        # stride 1, two-term splits: the producer / consumer kernel (4-row tiles, 512-thread blocks, one per CU)
+        pc = spec.stride == 1 and prec != 'bf16x6' and WGRAD_PC and spec.k == 3
+        # pixel tiles of 8 x 16 for the single-role 3x3 stride-1 gradient, 4 x 16 otherwise (as mt_wgrad_halo_try_launch)
+        trows = 8 if (not pc and spec.k == 3 and spec.stride == 1 and prec != 'bf16x6'
                       and os.environ.get('MT355_WGRAD3_TALL', '1') != '0') else 4
         ntiles = dv.N * ((dv.H + trows - 1) // trows) * ((dv.W + 15) // 16)
-        d.splits = max(1, min((512 + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 256))
+        want = WGRAD_PC_BLOCKS if pc else 512        # blocks in flight: one 512-thread block per CU for pc
+        d.splits = max(1, min((want + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 256))
     else:
         d.splits = _splits(tiles * t, pixels)
     d.algo = 0 if USE_HALO else 1
@@ -656,7 +661,8 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     d.d_amax, keep1 = _amax_ptr(prec, da, dv)
     d.g_amax, keep2 = _amax_ptr(prec, ga, gv)
     if halo:
-        kname = f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else (1 if rows5 else "3+2")},{_HTAG[prec]}>'
+        kname = (f'wgrad_pc_kernel<{spec.k},{"3" if spec.k == 3 else "2+2+1"},{_HTAG[prec]}>' if pc else
+                 f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else (1 if rows5 else "3+2")},{_HTAG[prec]}>')
     else:
         kname = ('wgrad_kernel' if prec == 'f32' else 'wgrad_split_kernel') + f'<{wcfg}{_KTAG[prec]}>'
     useful = spec.cin * spec.cout if sub_blocks is None else sum(sb[1] * sb[2] for sb in sub_blocks)
