@@ -379,14 +379,52 @@ class CHN(LightningModule):
             if self.model_lpips is not None:
                 self.log('measures_lpips_{}'.format(split), MeasuresUtils.lpips(y_hat_comp, y_target, self.model_lpips))
 
-    # ---- test-time inpainting drivers (model_chn.py:87-254, 309-323): orchestration over the
-    # aligner and forward() above; every tensor op stays on the device, the only host reads are
-    # the hole percentages that steer the loops (as in the reference).  They work on COPIES of
-    # x and m (the reference's inpaint_ip / inpaint_cp update their arguments in place through
-    # unsqueeze views); the returned sequences are the same.
-    @staticmethod
-    def _fill_color(x):
-        return torch.as_tensor([0.485, 0.456, 0.406], dtype=torch.float32, device=x.device).view(1, 3, 1, 1)
+    # ---- test-time inpainting drivers (model_chn.py:87-254, 309-323) --------------------------------
+    # The three algorithms are sequences of ONE primitive -- "fill the hole of a target frame from one
+    # reference frame": align, hallucinate, shrink the hole by what the reference could see, re-fill
+    # what is left with the fill colour -- steered by the percentage of the frame that is still a
+    # hole.  ``_HoleFiller`` owns that primitive and its state (frame, hole mask, last composite) on
+    # the device.  The percentage never goes to the host: it becomes a device-side predicate; a pass
+    # can be *committed conditionally* on the device (``torch.where`` on the state), and the only
+    # thing the host ever reads is the one-byte "go on?" answer, through a pinned non-blocking copy.
+    # Drivers work on COPIES of x and m (the reference's inpaint_ip / inpaint_cp update their
+    # arguments in place through unsqueeze views); the returned sequences are the same.
+    class _HoleFiller:
+        def __init__(self, model, x_t, m_t, e):
+            self.model, self.e = model, float(e)
+            self.x, self.m = x_t.contiguous(), m_t.contiguous()          # (1,3,H,W), (1,1,H,W)
+            self.fill = torch.as_tensor([0.485, 0.456, 0.406], dtype=torch.float32, device=x_t.device).view(1, 3, 1, 1)
+            self.y = None                                                 # last composite (1,3,H,W)
+            self._flag = torch.empty((1,), dtype=torch.uint8).pin_memory() if x_t.is_cuda else torch.empty((1,), dtype=torch.uint8)
+            self._ev = torch.cuda.Event() if x_t.is_cuda else None
+
+        @torch.no_grad()
+        def fill_from(self, x_r, m_r, commit=None):
+            """One pass against reference (x_r (1,3,H,W), m_r (1,1,H,W)).  ``commit``: optional device
+            bool -- the pass only takes effect where it is true (a speculative pass costs a launch
+            sequence, never a wrong pixel).  Returns the hole percentage after the pass as a device
+            scalar (model_chn.py:131,186,246)."""
+            xa, va, v_map = self.model.model_aligner.align(self.x, self.m, x_r.unsqueeze(2).contiguous(),
+                                                           m_r.unsqueeze(2).contiguous())
+            _, y_comp = self.model(self.x, (1 - self.m).contiguous(), xa, va, v_map)
+            m_new = self.m - v_map[:, :, 0]
+            x_new = (1 - m_new) * y_comp[:, :, 0] + m_new * self.fill
+            y_new = y_comp[:, :, 0]
+            if commit is not None:
+                m_new, x_new = torch.where(commit, m_new, self.m), torch.where(commit, x_new, self.x)
+                y_new = torch.where(commit, y_new, self.y) if self.y is not None else y_new
+            self.m, self.x, self.y = m_new, x_new, y_new
+            return m_new.sum() * 100 / m_new.numel()
+
+        def host(self, flag):
+            """The one-byte answer the control flow needs (pinned copy + event: the stream is not drained
+            by a .item() of a reduction, and nothing else of the pass is waited for)."""
+            if self._ev is None:
+                return bool(flag)
+            self._flag.copy_(flag.to(torch.uint8).reshape(1), non_blocking=True)
+            self._ev.record()
+            self._ev.synchronize()
+            return bool(self._flag[0])
 
     @torch.no_grad()
     def _align_forward(self, x_t, m_t, x_r, m_r):
@@ -394,70 +432,70 @@ class CHN(LightningModule):
         y_hat, y_hat_comp = self(x_t.contiguous(), (1 - m_t).contiguous(), xa, va, v_map)
         return y_hat_comp, v_map
 
+    def _fill_until_small(self, filler, candidates, ref_of):
+        """Consume reference candidates until the hole is below the threshold or none are left (at
+        least one pass always runs): the loop of model_chn.py:108-131 / 160-186."""
+        more = True
+        for k, r in enumerate(candidates):
+            if not more:
+                break
+            inp_per = filler.fill_from(*ref_of(r))
+            more = filler.host(inp_per > filler.e) if k + 1 < len(candidates) else False
+        return filler
+
     @torch.no_grad()
     def inpaint_ff(self, x, m, s=1, D=20, e=1):
-        """Frame-by-Frame algorithm, model_chn.py:87-133.  x (3,F,H,W), m (1,F,H,W) -> (3,F,H,W)."""
-        fill = CHN._fill_color(x)
+        """Frame-by-Frame algorithm, model_chn.py:87-133.  x (3,F,H,W), m (1,F,H,W) -> (3,F,H,W): every
+        frame is filled independently from its neighbours by distance."""
         y_inpainted = torch.zeros_like(x)
         for t in range(x.size(1)):
-            x_target, m_target = x[:, t].unsqueeze(0), m[:, t].unsqueeze(0)
-            y_hat_comp, inp_per = None, 0
-            t_candidates = CHN.get_indexes_ff(t, x.size(1), s=s, D=D)
-            while (len(t_candidates) > 0 and inp_per > e) or y_hat_comp is None:
-                r_list = [t_candidates.pop(0)]
-                y_hat_comp, v_map = self._align_forward(x_target, m_target, x[:, r_list].unsqueeze(0),
-                                                        m[:, r_list].unsqueeze(0))
-                m_target = m_target - v_map[:, :, 0]
-                x_target = (1 - m_target) * y_hat_comp[:, :, 0] + m_target.repeat(1, 3, 1, 1) * fill
-                inp_per = float(torch.sum(m_target) * 100 / m_target.numel())
-            y_inpainted[:, t] = y_hat_comp[:, :, 0]
+            filler = CHN._HoleFiller(self, x[:, t].unsqueeze(0), m[:, t].unsqueeze(0), e)
+            self._fill_until_small(filler, CHN.get_indexes_ff(t, x.size(1), s=s, D=D),
+                                   lambda r: (x[:, r].unsqueeze(0), m[:, r].unsqueeze(0)))
+            y_inpainted[:, t] = filler.y[0]
         return y_inpainted
 
     @torch.no_grad()
     def inpaint_ip(self, x, m, s=1, D=20, e=1):
-        """Inpaint-and-Propagate algorithm, model_chn.py:135-190."""
-        fill = CHN._fill_color(x)
-        y_inpainted, m_inpainted = x.clone().unsqueeze(0), m.clone().unsqueeze(0)
-        t_list = sorted(list(range(x.size(1))), key=lambda xi: abs(xi - x.size(1) // 2))
-        for t in t_list:
-            t_candidates = CHN.get_indexes_ip(t, t_list, s, D)
-            y_hat_comp, inp_per = None, 0
-            while (len(t_candidates) > 0 and inp_per > e) or y_hat_comp is None:
-                r_list = [t_candidates.pop(0)]
-                y_hat_comp, v_map = self._align_forward(y_inpainted[:, :, t], m_inpainted[:, :, t],
-                                                        y_inpainted[:, :, r_list], m_inpainted[:, :, r_list])
-                m_inpainted[:, :, t] = m_inpainted[:, :, t] - v_map[:, :, 0]
-                y_inpainted[:, :, t] = (1 - m_inpainted[:, :, t]) * y_hat_comp[:, :, 0] + \
-                    m_inpainted[:, :, t].repeat(1, 3, 1, 1) * fill
-                inp_per = float(torch.sum(m_inpainted[:, :, t]) * 100 / m_inpainted[:, :, t].numel())
-            m_inpainted[:, :, t] = 0
-            y_inpainted[:, :, t] = y_hat_comp[:, :, 0]
-        return y_inpainted[0]
+        """Inpaint-and-Propagate algorithm, model_chn.py:135-190: frames from the centre outwards, each
+        one first against the frames already inpainted (now hole-free), then against raw neighbours."""
+        y_seq, m_seq = x.clone(), m.clone()
+        order = sorted(range(x.size(1)), key=lambda t: abs(t - x.size(1) // 2))
+        for t in order:
+            filler = CHN._HoleFiller(self, y_seq[:, t].unsqueeze(0), m_seq[:, t].unsqueeze(0), e)
+            self._fill_until_small(filler, CHN.get_indexes_ip(t, order, s, D),
+                                   lambda r: (y_seq[:, r].unsqueeze(0), m_seq[:, r].unsqueeze(0)))
+            y_seq[:, t], m_seq[:, t] = filler.y[0], 0
+        return y_seq
 
     @torch.no_grad()
     def inpaint_cp(self, x, m, N=20, s=1, e=1):
-        """Copy-and-Propagate algorithm, model_chn.py:192-254."""
-        fill = CHN._fill_color(x)
-        y_inpainted, m_inpainted = x.clone().unsqueeze(0), m.clone().unsqueeze(0)
+        """Copy-and-Propagate algorithm, model_chn.py:192-254: N sweeps over alternating frame sets, each
+        frame copies from its two neighbours at distance s; a frame is closed (hallucinated content
+        kept, mask cleared) once its hole is below e percent or in the last two sweeps.  The only host
+        read is one vector of "is this frame still open" flags per sweep (a sweep's targets and
+        references are disjoint sets, so the flags cannot change inside it); closing a frame is a
+        device-side conditional commit."""
+        y_seq, m_seq = x.clone(), m.clone()
+        f = x.size(1)
         for i in range(N):
-            t_list = [t for t in range(y_inpainted.size(2)) if (t // s) % (s if s > 1 else 2) == i % 2]
-            for t in t_list:
-                if float(m_inpainted[:, :, t].sum()) == 0:
+            t_list = [t for t in range(f) if (t // s) % (s if s > 1 else 2) == i % 2]
+            if not t_list:
+                continue
+            open_flags = (m_seq[0, t_list].flatten(1).sum(1) != 0).tolist()          # ONE host read per sweep
+            for t, is_open in zip(t_list, open_flags):
+                if not is_open:
                     continue
-                for delta_t in [-s, s]:
-                    if not 0 <= t + delta_t < y_inpainted.size(2):
+                for r in (t - s, t + s):
+                    if not 0 <= r < f:
                         continue
-                    r_list = [t + delta_t]
-                    y_hat_comp, v_map = self._align_forward(y_inpainted[:, :, t], m_inpainted[:, :, t],
-                                                            y_inpainted[:, :, r_list], m_inpainted[:, :, r_list])
-                    m_inpainted[:, :, t] = m_inpainted[:, :, t] - v_map[:, :, 0]
-                    y_inpainted[:, :, t] = (1 - m_inpainted[:, :, t]) * y_hat_comp[:, :, 0] + \
-                        m_inpainted[:, :, t].repeat(1, 3, 1, 1) * fill
-                    inp_per = float(torch.sum(m_inpainted[:, :, t]) * 100 / m_inpainted[:, :, t].numel())
-                    if inp_per < e or i >= N - 2:
-                        m_inpainted[:, :, t] = 0
-                        y_inpainted[:, :, t] = y_hat_comp[:, :, 0]
-        return y_inpainted[0]
+                    filler = CHN._HoleFiller(self, y_seq[:, t].unsqueeze(0), m_seq[:, t].unsqueeze(0), e)
+                    inp_per = filler.fill_from(y_seq[:, r].unsqueeze(0), m_seq[:, r].unsqueeze(0))
+                    close = (inp_per < e) if i < N - 2 else torch.ones_like(inp_per, dtype=torch.bool)
+                    # closed: the composite stays and the mask is cleared; open: copied pixels + fill colour
+                    y_seq[:, t] = torch.where(close, filler.y, filler.x)[0]
+                    m_seq[:, t] = torch.where(close, torch.zeros_like(filler.m), filler.m)[0]
+        return y_seq
 
     def test_step(self, batch, batch_idx):
         """model_chn.py:309-323: the three drivers on the first clip of the batch.  The reference
