@@ -1056,9 +1056,9 @@ __global__ __launch_bounds__(512, 1) void corr_fused_kernel(const float* ft, lon
   };
   const int nchunk = C / CKC;   // even, >= 4
   const int c_start = (2 * clip) % nchunk;
-  // channel offset of chunk c (rotated start); past the last chunk: beyond the descriptor's
-  // range, where a buffer load returns zeros without touching memory
-  auto choff = [&](int c) { int q = c + c_start; q = q >= nchunk ? q - nchunk : q; return c < nchunk ? q * CKC : (1 << 28); };
+  // channel offset of chunk c < nchunk (rotated start); the pipeline tail issues no loads at all
+  // (nothing relies on how an out-of-range soffset would be bounds-checked)
+  auto choff = [&](int c) { int q = c + c_start; q = q >= nchunk ? q - nchunk : q; return q * CKC; };
   // Group g keeps chunk c in register set (c + g) & 1 and runs one phase behind/ahead of the
   // other group:   g0: C0 | S1 | C1 | S2 | ...      g1: S1 | C0 | S2 | C1 | ...
   // (Ck = MFMAs of chunk k from image k&1, Sk = split+store of the group's share of chunk k)
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(512, 1) void corr_fused_kernel(const float* ft, lon
       if (cs < nchunk) {
         store(rt[h ^ 1], rr[h ^ 1], (h ^ 1) ^ g);
       }
-      load(rt[h ^ 1], rr[h ^ 1], choff(cs + 2));
+      if (cs + 2 < nchunk) load(rt[h ^ 1], rr[h ^ 1], choff(cs + 2));      // (wave-uniform: the tail issues no loads)
       __syncthreads();
     }
   }

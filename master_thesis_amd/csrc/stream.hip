@@ -208,6 +208,11 @@ struct WarpL {   // 5-D (B, C, F, H, W) addressing without materialising the F-f
   long wb, wf;         // vo
 };
 
+// float -> int of a corner / nearest coordinate: defined for every input (huge flows, NaN: the
+// result is far outside any image and fails the bounds tests; NaN maps to the lower clamp), and
+// leaves room for the "+ 1" of the second corner.  Values inside +-2^30 convert unchanged.
+__device__ __forceinline__ int coord_int(float f) { return (int)fminf(fmaxf(f, -1073741824.f), 1073741824.f); }
+
 __global__ void warp_fwd_kernel(const float* x, const float* v, const float* grid, WarpL L, int ac, float* xo, float* vo,
                                 int* idx) {
   const int H = L.H, W = L.W;
@@ -220,7 +225,7 @@ __global__ void warp_fwd_kernel(const float* x, const float* v, const float* gri
     const f32x2 g = *reinterpret_cast<const f32x2*>(grid + e * 2);
     const float ix = unnorm(g[0], W, ac), iy = unnorm(g[1], H, ac);
     const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const int x0 = coord_int(fx), y0 = coord_int(fy), x1 = x0 + 1, y1 = y0 + 1;
     const float wx1 = ix - fx, wy1 = iy - fy, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy;
     const float nw = wx0 * wy0, ne = wx1 * wy0, sw = wx0 * wy1, se = wx1 * wy1;
     const bool bx0 = x0 >= 0 && x0 < W, bx1 = x1 >= 0 && x1 < W, by0 = y0 >= 0 && y0 < H, by1 = y1 >= 0 && y1 < H;
@@ -238,7 +243,7 @@ __global__ void warp_fwd_kernel(const float* x, const float* v, const float* gri
     // nearest: nearbyint (ties to even), zeros outside
     const float rx = nearbyintf(ix), ry = nearbyintf(iy);
     const bool nin = rx >= 0.f && rx < (float)W && ry >= 0.f && ry < (float)H;
-    const int nx = nin ? (int)rx : -1, ny = nin ? (int)ry : -1;
+    const int nx = nin ? coord_int(rx) : -1, ny = nin ? coord_int(ry) : -1;
     if (vo) vo[b * L.wb + f * L.wf + pix] = nin ? v[b * L.vb + f * L.vf + (long)ny * W + nx] : 0.f;
     if (idx) {
       const bool cin = fabsf(fx) < 1e9f && fabsf(fy) < 1e9f;
@@ -262,7 +267,7 @@ __global__ void warp_bwd_grid_kernel(const float* x, const float* grid, const fl
     const f32x2 g = *reinterpret_cast<const f32x2*>(grid + e * 2);
     const float ix = unnorm(g[0], W, ac), iy = unnorm(g[1], H, ac);
     const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const int x0 = coord_int(fx), y0 = coord_int(fy), x1 = x0 + 1, y1 = y0 + 1;
     const float wx1 = ix - fx, wy1 = iy - fy, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy;
     const bool bx0 = x0 >= 0 && x0 < W, bx1 = x1 >= 0 && x1 < W, by0 = y0 >= 0 && y0 < H, by1 = y1 >= 0 && y1 < H;
     float gx = 0.f, gy = 0.f;
