@@ -63,8 +63,10 @@ enum mt_algo { MT_ALGO_AUTO = 0, MT_ALGO_IGEMM = 1 };
 /* Layout of mt_conv.wt: ROWS = [Cout_p][KH*KW][Cin_p] rows (mt_weight_pack /
  * mt_weight_pack_split: every kernel but the halo one); HALO = the per-tile LDS
  * images of mt_weight_pack_halo (required by, and only valid for, layers that
- * MT_ALGO_AUTO sends to the halo-tile kernel). */
-enum mt_wt_layout { MT_WT_ROWS = 0, MT_WT_HALO = 1 };
+ * MT_ALGO_AUTO sends to the halo-tile kernel); PLANES = the fragment stream of
+ * mt_weight_pack_planes (stride-2 3x3 / 5x5 layers with >= 64 channels on both sides,
+ * two-term split precisions: mt_weight_pack_planes_wanted). */
+enum mt_wt_layout { MT_WT_ROWS = 0, MT_WT_HALO = 1, MT_WT_PLANES = 2 };
 
 int mt_version(void);
 const char* mt_last_error(void);
@@ -219,7 +221,7 @@ typedef struct {
 } mt_amax_seg;
 int mt_absmax_segments(const mt_amax_seg* segs_dev, int32_t nseg, void* stream);
 
-enum mt_pack_kind { MT_PACK_SPLIT = 0, MT_PACK_HALO = 1 };
+enum mt_pack_kind { MT_PACK_SPLIT = 0, MT_PACK_HALO = 1, MT_PACK_PLANES = 2 /* flip holds `transposed` */ };
 typedef struct {
   const float* src;
   void* dst;
@@ -240,6 +242,18 @@ int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, int32_t T, 
 /* jobs_dev: njobs entries in device memory; equivalent to calling the single-pack
  * entry point of every job.  jobs_host: the same table in host memory (argument checks). */
 int mt_weight_pack_jobs(const mt_pack_job* jobs_dev, const mt_pack_job* jobs_host, int32_t njobs, void* stream);
+
+/* Stride-2 layers (Conv2d stride 2 / ConvTranspose2d stride 2 and their backward-data:
+ * model_dfpn.py:689-708, model_chn.py:525,527) on the halo-tile kernel: the strided gather
+ * (transposed == 0) walks the four parity planes of X as extra K chunks, the transposed gather
+ * (transposed == 1) runs one stride-1 window convolution per output parity class; either way only
+ * the taps that exist are multiplied.  The pack is the weight-fragment stream in the order the
+ * kernel consumes it; `transposed` must be the mt_conv.transposed of the launch that uses it. */
+int32_t mt_weight_pack_planes_wanted(int32_t AP, int32_t BP, int32_t T, int32_t precision);
+int64_t mt_weight_pack_planes_elems(int32_t AP, int32_t BP, int32_t T, int32_t transposed);
+int mt_weight_pack_planes(const float* src, int32_t A, int32_t B, int32_t T, int64_t sa, int64_t sb,
+                          int64_t st, void* dst, int32_t AP, int32_t BP, int32_t precision,
+                          int32_t transposed, const float* w_amax, void* stream);
 
 /* One K-part of a STACKED weight image: the B (input-channel) axis of the packed
  * tiles is the concatenation of several sources (e.g. the layers whose output

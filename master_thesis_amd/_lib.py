@@ -86,6 +86,9 @@ SIGNATURES = {
     'mt_weight_pack_split': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp, _vp],
     'mt_weight_pack_halo': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp, _vp],
     'mt_weight_pack_halo_part': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp, i32, i32, _vp],
+    'mt_weight_pack_planes_wanted': [i32, i32, i32, i32],
+    'mt_weight_pack_planes_elems': [i32, i32, i32, i32],
+    'mt_weight_pack_planes': [_vp, i32, i32, i32, i64, i64, i64, _vp, i32, i32, i32, i32, _vp, _vp],
     'mt_absmax': [_P(View), _vp, _vp],
     'mt_absmax_segments': [_vp, i32, _vp],
     'mt_weight_pack_jobs': [_vp, _vp, i32, _vp],
@@ -124,7 +127,8 @@ SIGNATURES = {
     'mt_comm_destroy': [_vp],
     'mt_allreduce_sum_f32': [_vp, _vp, i64, _vp],
 }
-_RESTYPES = {'mt_last_error': C.c_char_p, 'mt_wgrad_slab_floats': i64, 'mt_weight_pack_halo_elems': i64}
+_RESTYPES = {'mt_last_error': C.c_char_p, 'mt_wgrad_slab_floats': i64, 'mt_weight_pack_halo_elems': i64,
+             'mt_weight_pack_planes_elems': i64}
 
 _lib = None
 

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmt355.so')
-SOURCES = [('conv.hip', []), ('conv_halo.hip', []), ('conv_halo_wgrad.hip', []), ('conv_halo_wino.hip', []), ('stream.hip', ['-ffp-contract=off']),
+SOURCES = [('conv.hip', []), ('conv_halo.hip', []), ('conv_halo_wgrad.hip', []), ('conv_halo_wino.hip', []), ('conv_halo_planes.hip', []), ('stream.hip', ['-ffp-contract=off']),
            ('metrics.hip', []), ('api.cpp', []), ('comm.cpp', [])]
 
 
@@ -37,7 +37,7 @@ def build(force=False, verbose=True):
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)
-        with ThreadPoolExecutor(max_workers=min(7, len(cmds))) as ex:
+        with ThreadPoolExecutor(max_workers=min(8, len(cmds))) as ex:
             list(ex.map(run, cmds))
     if force or _stale(LIB, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl']

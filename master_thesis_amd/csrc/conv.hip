@@ -809,9 +809,11 @@ int wgrad_cfg(const mt_wgrad* d, int* atiles, int* btiles, int* cfg) {
 }  // namespace
 
 int mt_halo_try_launch(const mt_conv* d, void* stream);   // conv_halo.hip
+int mt_halo_planes_try_launch(const mt_conv* d, void* stream);   // conv_halo_planes.hip
 
 extern "C" int mt_conv_run(const mt_conv* d, void* stream) {
   if (d && d->algo == MT_ALGO_AUTO && mt_halo_try_launch(d, stream)) return mt_check_launch("mt_conv_run(halo)");
+  if (d && d->algo == MT_ALGO_AUTO && mt_halo_planes_try_launch(d, stream)) return mt_check_launch("mt_conv_run(planes)");
   MT_REQUIRE(!d || d->wt_layout == MT_WT_ROWS, "mt_conv: halo weight tiles given to a layer the halo kernel does not take");
   ConvK k;
   int rc = fill_convk(d, &k);

@@ -375,6 +375,69 @@ __device__ __forceinline__ void pack_halo_wino_body(const float* src, int A, int
   }
 }
 
+// ---- stride-2 layers as window convolutions over "units" (conv_halo_planes.hip) -----------------
+// Unit u = parity plane (a, b) = (u >> 1, u & 1) of X for the strided gather, output parity class
+// (A, B) for the transposed gather.  Window position (dy + 1) * 3 + (dx + 1), dy, dx in {-1, 0, 1},
+// stands for the kernel tap  kh = 2 dy + a + pad  (strided)  /  kh = A + pad - 2 dy  (transposed).
+struct UnitTaps { unsigned mask[4]; signed char src[4][9]; int ntaps[4]; };
+
+__host__ __device__ inline UnitTaps unit_taps(int transposed, int K, int pad) {
+  UnitTaps t = {};
+  for (int u = 0; u < 4; ++u) {
+    const int a = u >> 1, b = u & 1;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int kh = transposed ? a + pad - 2 * dy : 2 * dy + a + pad;
+        const int kw = transposed ? b + pad - 2 * dx : 2 * dx + b + pad;
+        const int wpos = (dy + 1) * 3 + (dx + 1);
+        t.src[u][wpos] = -1;
+        if (kh >= 0 && kh < K && kw >= 0 && kw < K) {
+          t.mask[u] |= 1u << wpos;
+          t.src[u][wpos] = (signed char)(kh * K + kw);
+          ++t.ntaps[u];
+        }
+      }
+  }
+  return t;
+}
+
+// Weight fragments in the order igemm_halo_planes_kernel consumes them:
+// dst[frag = (unit, chunk, tap of the unit's mask)][ntile][wn WN][kstep 2][plane 2][lane 64][8]
+__device__ __forceinline__ void pack_planes_body(const float* src, int A, int B, long sa, long sb, long st, __bf16* dst,
+                                                 int nchunk, int ntile, int WN, const float* wamax, const UnitTaps& t) {
+  const float sc = wamax ? pow2_scale(*wamax) : 1.f;
+  const long nfrag = (long)(t.ntaps[0] + t.ntaps[1] + t.ntaps[2] + t.ntaps[3]) * nchunk;
+  const long total = nfrag * ntile * WN * 2 * 64 * 8;      // elements per plane
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), ks = (int)((e >> 9) & 1);
+    long r = e >> 10;
+    const int wv = (int)(r % WN); r /= WN;
+    const int nt = (int)(r % ntile); r /= ntile;
+    const long fidx = r;
+    int u = 0;
+    long f = fidx;
+    while (u < 3 && f >= (long)t.ntaps[u] * nchunk) { f -= (long)t.ntaps[u] * nchunk; ++u; }
+    const int ch = (int)(f / t.ntaps[u]), ti = (int)(f % t.ntaps[u]);
+    unsigned m = t.mask[u];
+    for (int s = 0; s < ti; ++s) m &= m - 1;
+    const int tap = t.src[u][__ffs((int)m) - 1];
+    const int a = (nt * WN + wv) * 32 + (lane & 31), b = ch * 32 + ks * 16 + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (a < A && b < B) v = src[a * sa + b * sb + tap * st];
+    __bf16* o = dst + ((((fidx * ntile + nt) * WN + wv) * 2 + ks) * 2) * 512 + lane * 8 + j;
+    if (wamax) {
+      v *= sc;
+      const _Float16 h = (_Float16)v;
+      o[0] = __builtin_bit_cast(__bf16, h);
+      o[512] = __builtin_bit_cast(__bf16, (_Float16)(v - (float)h));
+    } else {
+      const __bf16 h = (__bf16)v;
+      o[0] = h;
+      o[512] = (__bf16)(v - (float)h);
+    }
+  }
+}
+
 // packed weights for the generic split kernels: dst[plane][a][Kp] (see mt_weight_pack_split)
 __device__ __forceinline__ void pack_split_body(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
                                          int AP, int BP, int Kp, int NS, int flip, const float* wamax) {

@@ -502,6 +502,12 @@ __global__ void weight_pack_jobs_kernel(const mt_pack_job* jobs) {
   const mt_pack_job j = jobs[blockIdx.y];
   const int NS = j.precision == MT_PREC_BF16X6 ? 3 : 2;
   __bf16* dst = reinterpret_cast<__bf16*>(j.dst);
+  if (j.kind == MT_PACK_PLANES) {          // stride-2 layer: fragments in the planes kernel's consumption order
+    const int K = j.T == 9 ? 3 : 5, BNp = j.AP > 64 ? 128 : 64;
+    const UnitTaps t = unit_taps(j.flip, K, K / 2);
+    pack_planes_body(j.src, j.A, j.B, j.sa, j.sb, j.st, dst, j.BP / 32, (j.AP + BNp - 1) / BNp, BNp / 32, j.w_amax, t);
+    return;
+  }
   if (j.kind == MT_PACK_SPLIT) {
     pack_split_body(j.src, j.A, j.B, j.T, j.sa, j.sb, j.st, dst, j.AP, j.BP, ((j.T * j.BP + 31) / 32) * 32, NS, j.flip,
                     j.w_amax);
@@ -614,6 +620,9 @@ extern "C" int mt_weight_pack_jobs(const mt_pack_job* jobs_dev, const mt_pack_jo
       MT_REQUIRE((j.BP & 7) == 0 && j.b_off >= 0 && j.b_off % CK == 0 && j.b_off + j.BP <= j.BP_total &&
                      (j.b_off + j.BP == j.BP_total || j.BP % CK == 0),
                  "mt_weight_pack_jobs: job %d: K part", i);
+    } else if (j.kind == MT_PACK_PLANES) {
+      MT_REQUIRE((j.T == 9 || j.T == 25) && mt_weight_pack_planes_wanted(j.AP, j.BP, j.T, j.precision) && (j.flip == 0 || j.flip == 1),
+                 "mt_weight_pack_jobs: job %d: not a shape of the planes kernel", i);
     } else {
       MT_REQUIRE(j.kind == MT_PACK_SPLIT, "mt_weight_pack_jobs: job %d: kind", i);
     }

@@ -293,7 +293,10 @@ def _job(src_ptr, a, b, t, sa, sb, st, dst, ap, bp, prec, flip, wa, kind, bp_tot
 
 def _run_job(j):
     """Single-launch execution of one pack job (first use of a pack)."""
-    if j.kind == 1:
+    if j.kind == 2:
+        L.call('mt_weight_pack_planes', j.src, j.A, j.B, j.T, j.sa, j.sb, j.st, j.dst, j.AP, j.BP, j.precision, j.flip,
+               j.w_amax, L.stream_ptr())
+    elif j.kind == 1:
         L.call('mt_weight_pack_halo_part', j.src, j.A, j.B, j.T, j.sa, j.sb, j.st, j.dst, j.AP, j.BP, j.precision, j.flip,
                j.w_amax, j.BP_total, j.b_off, L.stream_ptr())
     else:
@@ -301,7 +304,17 @@ def _run_job(j):
                j.w_amax, L.stream_ptr())
 
 
-def _pack(w, a_dim, kind, prec, flip=False, halo=False):
+PLANES = os.environ.get('MT355_PLANES', '1') != '0'      # mirrors halo_planes_enabled() in conv_halo_planes.hip
+
+
+def planes_eligible(stride, k, cin_p, cout_p, prec, ups=0):
+    """Mirror of mt_halo_planes_try_launch: stride-2 3x3 / 5x5 layers with >= 64 channels on both
+    sides run as window convolutions over parity planes / classes on the halo-tile kernel."""
+    return (PLANES and USE_HALO and stride == 2 and k in (3, 5) and ups == 0 and prec in ('f16x3', 'bf16x3')
+            and bool(L.load().mt_weight_pack_planes_wanted(cout_p, cin_p, k * k, _PREC[prec])))
+
+
+def _pack(w, a_dim, kind, prec, flip=False, halo=False, planes=None):
     """Packed copy of a conv weight for precision ``prec``: rows
     [AP][T][BP] (fp32 / bf16 planes) or, for the halo kernel, per-tile LDS
     images.  ``a_dim`` selects which of the two leading dims of ``w`` becomes
@@ -321,10 +334,17 @@ def _pack(w, a_dim, kind, prec, flip=False, halo=False):
             L.call('mt_weight_pack', L.ptr(w), a, b, t, sa, sb, 1, L.ptr(out), cpad(a), cpad(b), L.stream_ptr())
             hit = _pack_cache[key] = (out, w)
         return hit[0], None
-    key = (w.data_ptr(), w._version, kind, halo, prec)
+    key = (w.data_ptr(), w._version, kind, halo, prec, planes)
     ent = _packs.get(key)
     if ent is None:
         wa = _weight_amax(w) if prec == 'f16x3' else None
+        if planes is not None:      # stride-2 layer: fragment stream of the planes kernel (planes = mt_conv.transposed)
+            n = L.load().mt_weight_pack_planes_elems(cpad(a), cpad(b), t, planes)
+            out = torch.zeros((n,), device=w.device, dtype=torch.bfloat16)
+            job = _job(w.data_ptr(), a, b, t, sa, sb, 1, out, cpad(a), cpad(b), prec, bool(planes), wa, 2)
+            _run_job(job)
+            ent = _packs[key] = _PackEntry(out, wa, [job], [w])
+            return ent.out, ent.wa
         if halo:
             n = L.load().mt_weight_pack_halo_elems(cpad(a), cpad(b), t, _PREC[prec])
             out = torch.zeros((n,), device=w.device, dtype=torch.bfloat16)   # (the image may be shorter than the bound)
@@ -499,9 +519,11 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
     d.x, d.y = xv, view_of(out)
     halo = halo_eligible(spec.kind == 'c', spec.stride, spec.k, xv.C)
     prec = eff_precision(halo)
-    packed, wa = _pack(w, 0 if spec.kind == 'c' else 1, 'f', prec, halo=halo)
+    transposed = 0 if spec.kind == 'c' else 1
+    planes = planes_eligible(spec.stride, spec.k, xv.C, out.shape[3], prec, spec.ups)
+    packed, wa = _pack(w, 0 if spec.kind == 'c' else 1, 'f', prec, halo=halo, planes=transposed if planes else None)
     d.wt = packed.data_ptr()
-    d.wt_layout = 1 if halo else 0
+    d.wt_layout = 2 if planes else (1 if halo else 0)
     pb = _pad_bias(b, spec.cout)
     d.bias = pb.data_ptr() if pb is not None else None
     d.KH = d.KW = spec.k
@@ -520,7 +542,9 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
         flops = 2.0 * n * ho * wo * spec.cin * spec.cout * spec.k * spec.k
     else:
         flops = 2.0 * n * h * w_ * spec.cin * spec.cout * spec.k * spec.k
-    with _Prof(_kname(_igemm_name(d.y.C, halo, prec, xv.C), spec.k), flops):
+    name = f'igemm_halo_planes_kernel<{spec.k},s2,{"t" if transposed else "c"}>' if planes else \
+        _kname(_igemm_name(d.y.C, halo, prec, xv.C), spec.k)
+    with _Prof(name, flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
     return out
 
@@ -541,10 +565,17 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     if packed is not None:      # a stacked image from pack_stacked_bwd (halo-tile kernels only)
         assert as_fwd
         packed, wa = packed
+        stacked = True
     else:
-        packed, wa = _pack(w, 1 if spec.kind == 'c' else 0, 'bflip' if as_fwd else 'b', prec, flip=as_fwd, halo=as_fwd)
+        stacked = False
+    planes = False
+    if not stacked:
+        transposed_b = 0 if (spec.kind != 'c' or as_fwd) else 1
+        planes = (not as_fwd) and planes_eligible(spec.stride, spec.k, dz.shape[3], yv.C, prec)
+        packed, wa = _pack(w, 1 if spec.kind == 'c' else 0, 'bflip' if as_fwd else 'b', prec, flip=as_fwd, halo=as_fwd,
+                           planes=transposed_b if planes else None)
     d.wt = packed.data_ptr()
-    d.wt_layout = 1 if as_fwd else 0
+    d.wt_layout = 2 if planes else (1 if as_fwd else 0)
     d.bias = None
     d.KH = d.KW = spec.k
     d.stride, d.pad, d.ups = spec.stride, spec.pad, 0
@@ -561,7 +592,9 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     d.y_amax, keep_y = _out_amax(prec, y_amax, yv._src)
     side = d.x if spec.kind == 'c' else yv          # the conv's output side
     flops = 2.0 * side.N * side.H * side.W * spec.cin * spec.cout * spec.k * spec.k
-    with _Prof(_kname(_igemm_name(yv.C, as_fwd, prec, dzv.C), spec.k), flops):
+    name = f'igemm_halo_planes_kernel<{spec.k},s2,{"t" if d.transposed else "c"}>' if planes else \
+        _kname(_igemm_name(yv.C, as_fwd, prec, dzv.C), spec.k)
+    with _Prof(name, flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): collects the rocprofv3 evidence bench.py's numbers are
 # judged against and writes compact summaries under gpurun_out/profiles_<tag>/ :
-#   <tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-chn` (DFPN cfg2 only, so per-kernel averages are those of the roofline line)
+#   <tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-chn` (DFPN cfg2 only, so per-kernel averages are those of the roofline line)
 #   <tag>_bench_under_rocprof.json the bench line printed in that run
 #   <tag>_pmc_hbm_traffic.txt      FETCH_SIZE / WRITE_SIZE (separate passes) per kernel, DFPN cfg2 step (eager) + correlation micro-bench
 #   <tag>_pmc_mfma_util.txt        matrix-pipe utilisation and sustained clock per kernel (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE)
@@ -11,13 +11,13 @@ export TMPDIR=/tmp
 tag=${1:-r01}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-chn > $out/${tag}_bench_under_rocprof.json 2> $out/stats.err || echo "stats run failed"
+rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-check --no-chn > $out/${tag}_bench_under_rocprof.json 2> $out/stats.err || echo "stats run failed"
 cp $(find $out/stats -name '*kernel_stats.csv' | head -1) $out/${tag}_bench_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $out/pmc_$c -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-chn --no-graph > $out/pmc_$c.json 2> $out/pmc_$c.err || echo "pmc $c failed"
+  rocprofv3 --pmc $c --kernel-trace -d $out/pmc_$c -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-check --no-chn --no-graph > $out/pmc_$c.json 2> $out/pmc_$c.err || echo "pmc $c failed"
 done
 # matrix-pipe utilisation: MFMA busy cycles (summed over the 1024 SIMDs) against the GPU-active cycles
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/pmc_MFMA -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-chn --no-graph > $out/pmc_MFMA.json 2> $out/pmc_MFMA.err || echo "pmc MFMA failed"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/pmc_MFMA -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-check --no-chn --no-graph > $out/pmc_MFMA.json 2> $out/pmc_MFMA.err || echo "pmc MFMA failed"
 python3 - "$out" "$tag" <<'PY'
 import csv, glob, sys, collections
 out, tag = sys.argv[1], sys.argv[2]
@@ -41,7 +41,7 @@ for k in fe:
     rows.append((mb * n, k, n, f, w, mb, ms))
 rows.sort(reverse=True)
 with open(f'{out}/{tag}_pmc_hbm_traffic.txt', 'w') as o:
-    o.write('# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-chn --no-graph\n')
+    o.write('# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-check --no-chn --no-graph\n')
     o.write('# (DFPN cfg2 steps, eager launches, + the 2048-pair correlation micro-benchmark).  Units: KB per dispatch; gfx950 correction\n')
     o.write('# (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of a wide coalesced stream -> bytes = (2*FETCH + WRITE) * 1024\n')
     o.write('kernel,launches,avg_FETCH_SIZE_KB,avg_WRITE_SIZE_KB,corrected_MB_per_launch,avg_ms_under_pmc,corrected_GB_per_s\n')
@@ -71,7 +71,7 @@ if f:
         rows.append((b, k, len(busy[k]), ms, util, clk))
     rows.sort(reverse=True)
     with open(f'{out}/{tag}_pmc_mfma_util.txt', 'w') as o:
-        o.write('# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace, bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-chn --no-graph\n')
+        o.write('# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace, bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-check --no-chn --no-graph\n')
         o.write('# mfma_util = MFMA busy cycles / (GPU-active cycles per XCD x 1024 SIMDs); clock = active cycles per XCD / duration.\n')
         o.write('# The dense 16-bit peak (2.5 PFLOP/s) assumes util 1.0 at 2.4 GHz; on random fp16 data a pure-MFMA loop holds ~1.62 GHz (scratch/lab/mfma_peak.hip).\n')
         o.write('kernel,launches,total_ms_under_pmc,mfma_util,clock_GHz\n')
