@@ -30,6 +30,7 @@ struct PlanesK {
   long xsh, xsw;        // row / pixel stride of the input views
   int Hc, Wc;           // output positions (i, j) of this launch
   int omul, oya, oxa;   // output pixel = (i * omul + oya, j * omul + oxa)
+  int zclasses;         // 1: blockIdx.z = output parity class (A, B): unit z alone, (oya, oxa) = (A, B), Hc / Wc per class
 };
 
 namespace {
@@ -55,6 +56,13 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_planes_kernel(ConvK p, Plan
   const float scA = FMT ? pow2_scale(*p.xamax) : 1.f;
   const float inv = FMT ? 1.f / (scA * pow2_scale(*p.wamax)) : 1.f;
   const float* xin = p.x + (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
+  // transposed gather: the four output classes share one launch (their tap counts differ: 1, 2, 2, 4 of a
+  // 3 x 3 -- run one after the other they would each pay their own ramp-up and tail)
+  // (the kernel argument itself is never written: a modified copy would live in scratch memory)
+  const int ubase = q.zclasses ? blockIdx.z : 0;
+  const int oya = q.zclasses ? (int)(blockIdx.z >> 1) : q.oya, oxa = q.zclasses ? (int)(blockIdx.z & 1) : q.oxa;
+  const int Hc = q.zclasses ? (p.Ho - oya + 1) >> 1 : q.Hc, Wc = q.zclasses ? (p.Wo - oxa + 1) >> 1 : q.Wc;
+  if (ty0 >= Hc || tx0 >= Wc) return;
 
   // halo staging coordinates (window origin -1): the same for every unit, only the bounds differ
   long h_off[RH];
@@ -70,8 +78,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_planes_kernel(ConvK p, Plan
   }
   f32x4 rh[RH];
   auto load_halo = [&](int unit, int c0) {
-    const float* xu = xin + q.u[unit].xoff;
-    const int uh = q.u[unit].H, uw = q.u[unit].W;
+    const float* xu = xin + q.u[ubase + unit].xoff;
+    const int uh = q.u[ubase + unit].H, uw = q.u[ubase + unit].W;
 #pragma unroll
     for (int i = 0; i < RH; ++i) {
       const int c4 = (tid + 256 * i) % F4;
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_planes_kernel(ConvK p, Plan
   for (int a = 0; a < TM; ++a) a_base[a] = ((2 * (wm * TM + a) + (li >> 4)) * HW_ + apx) * LD + 8 * lh;
 
   const int nvc = q.nunits * nchunk;        // virtual chunks: (unit, channel chunk)
-  int widx = q.u[0].frag0;
+  int widx = q.u[ubase].frag0;
   load_halo(0, 0);
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) load_B(widx, ks);
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_planes_kernel(ConvK p, Plan
     const int unit = vc / nchunk;
     const int nunit = (vc + 1) / nchunk, nc0 = ((vc + 1) - nunit * nchunk) * CK;
     const __bf16* hb = sH + cur * HALO_E;
-    unsigned m = q.u[unit].mask;
+    unsigned m = q.u[ubase + unit].mask;
     bool first = true;
     while (m) {
       const int wpos = __builtin_ctz(m);
@@ -171,8 +179,8 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_planes_kernel(ConvK p, Plan
       const int i32 = row & 31;
       const int i = ty0 + (row >> 4), j = tx0 + (i32 < 16 ? i32 : ((i32 - HW_) & 15));
       // (positions past the class's extent map past Ho / Wo or are cut here)
-      oy = i < q.Hc ? i * q.omul + q.oya : p.Ho;
-      ox = j < q.Wc ? j * q.omul + q.oxa : p.Wo;
+      oy = i < Hc ? i * q.omul + oya : p.Ho;
+      ox = j < Wc ? j * q.omul + oxa : p.Wo;
     }));
   }
   if (p.yamax) raise_amax(p.yamax, vmax);
@@ -238,17 +246,17 @@ int mt_halo_planes_try_launch(const mt_conv* d, void* stream) {
   const UnitTaps t = unit_taps(d->transposed, d->KH, d->pad);
   const int nchunk = k.C / 32;
   PlanesK q = {};
-  auto launch = [&](int Hc, int Wc) {
+  auto launch = [&](int Hc, int Wc, int nz) {
     q.Hc = Hc; q.Wc = Wc;
     const int tiles_y = (Hc + 7) / 8, tiles_x = (Wc + 15) / 16;
     const unsigned nt = (unsigned)k.N * tiles_y * tiles_x;
     if (nt == 0) return;
     if (k.Co > 64) {
-      if (fmt) hipLaunchKernelGGL((igemm_halo_planes_kernel<1, 1>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, q, tiles_y, tiles_x);
-      else hipLaunchKernelGGL((igemm_halo_planes_kernel<0, 1>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, q, tiles_y, tiles_x);
+      if (fmt) hipLaunchKernelGGL((igemm_halo_planes_kernel<1, 1>), dim3(nt, (k.Co + 127) / 128, nz), dim3(256), 0, s, k, q, tiles_y, tiles_x);
+      else hipLaunchKernelGGL((igemm_halo_planes_kernel<0, 1>), dim3(nt, (k.Co + 127) / 128, nz), dim3(256), 0, s, k, q, tiles_y, tiles_x);
     } else {
-      if (fmt) hipLaunchKernelGGL((igemm_halo_planes_kernel<1, 2>), dim3(nt, 1), dim3(256), 0, s, k, q, tiles_y, tiles_x);
-      else hipLaunchKernelGGL((igemm_halo_planes_kernel<0, 2>), dim3(nt, 1), dim3(256), 0, s, k, q, tiles_y, tiles_x);
+      if (fmt) hipLaunchKernelGGL((igemm_halo_planes_kernel<1, 2>), dim3(nt, 1, nz), dim3(256), 0, s, k, q, tiles_y, tiles_x);
+      else hipLaunchKernelGGL((igemm_halo_planes_kernel<0, 2>), dim3(nt, 1, nz), dim3(256), 0, s, k, q, tiles_y, tiles_x);
     }
   };
   if (!d->transposed) {
@@ -263,21 +271,18 @@ int mt_halo_planes_try_launch(const mt_conv* d, void* stream) {
       q.u[u].frag0 = f0;
       f0 += t.ntaps[u] * nchunk;
     }
-    launch(k.Ho, k.Wo);
+    launch(k.Ho, k.Wo, 1);
   } else {
-    // four launches: output parity class (A, B), one unit each over the whole X
-    q.nunits = 1; q.xsh = k.xsh; q.xsw = k.xsw; q.omul = 2;
+    // ONE launch, blockIdx.z = output parity class (A, B): one unit each over the whole X
+    q.nunits = 1; q.xsh = k.xsh; q.xsw = k.xsw; q.omul = 2; q.zclasses = 1;
     int f0 = 0;
     for (int c = 0; c < 4; ++c) {
-      const int A = c >> 1, B = c & 1;
-      q.u[0].xoff = 0; q.u[0].H = k.H; q.u[0].W = k.W;
-      q.u[0].mask = t.mask[c];
-      q.u[0].frag0 = f0;
+      q.u[c].xoff = 0; q.u[c].H = k.H; q.u[c].W = k.W;
+      q.u[c].mask = t.mask[c];
+      q.u[c].frag0 = f0;
       f0 += t.ntaps[c] * nchunk;
-      q.oya = A; q.oxa = B;
-      if (t.ntaps[c] == 0) continue;       // (cannot happen for k = 3, 5)
-      launch((k.Ho - A + 1) / 2, (k.Wo - B + 1) / 2);
     }
+    launch((k.Ho + 1) / 2, (k.Wo + 1) / 2, 4);
   }
   return 1;
 }
