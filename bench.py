@@ -156,7 +156,7 @@ def pmc_traffic(label):
     if not files:
         return none
     rows = open(files[-1]).read().splitlines()
-    want = label.replace(',bf16', ',0').replace(',f16', ',1').replace(' ', '')
+    want = label.replace('bf16', '0').replace('f16', '1').replace(' ', '')
     for row in rows:
         if row.startswith('#') or '>' not in row:
             continue
@@ -430,7 +430,7 @@ def run_rank(args):
         name, (launches, kms, kfl) = max(agg.items(), key=lambda kv: kv[1][1])
         ach = kfl / (kms * 1e-3) / 1e12
         # MFMA products issued per fp32 multiply-add by the kernel's arithmetic
-        per = 3 if (',f16' in name or ',2,bf16' in name or name.endswith(',2>') or '_rb_' in name or 'wino' in name) else \
+        per = 3 if ('f16' in name or ',2,bf16' in name or name.endswith(',2>') or '_rb_' in name or 'wino' in name) else \
             (6 if 'split' in name or 'halo' in name else 1)
         peak = PEAK_FP32_MFMA_TFLOPS if per == 1 else PEAK_16BIT_MFMA_TFLOPS / per
         out['roofline'] = {'kernel': name, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',

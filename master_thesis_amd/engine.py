@@ -104,8 +104,15 @@ def _igemm_name(co, halo, prec, cin_p=0):
     return f'{base}<{cfg}{_KTAG[prec]}>'
 
 
-def _kname(template, k):
-    return template.replace('{rbw}', 'wino' if (k == 3 and HALO_WINO) else 'rb').replace('{k}', str(k))
+def _kname(template, k, co=0, ho=0):
+    """Profiling label of a register-B shape: the Winograd kernels take the 3 x 3 layers
+    (igemm_wino16_kernel: Cout > 64 and more than 8 output rows)."""
+    if k == 3 and HALO_WINO and '{rbw}' in template:
+        fmt = 'f16' if ',f16' in template else 'bf16'
+        if co > 64 and ho > 8:
+            return f'igemm_wino16_kernel<{fmt}>'
+        return f'igemm_halo_wino_kernel<{fmt},{1 if co > 64 else 2}>'
+    return template.replace('{rbw}', 'rb').replace('{k}', str(k))
 
 
 class _Prof:
@@ -543,7 +550,7 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
     else:
         flops = 2.0 * n * h * w_ * spec.cin * spec.cout * spec.k * spec.k
     name = f'igemm_halo_planes_kernel<{spec.k},s2,{"t" if transposed else "c"}>' if planes else \
-        _kname(_igemm_name(d.y.C, halo, prec, xv.C), spec.k)
+        _kname(_igemm_name(d.y.C, halo, prec, xv.C), spec.k, d.y.C, d.y.H)
     with _Prof(name, flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
     return out
@@ -593,7 +600,7 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     side = d.x if spec.kind == 'c' else yv          # the conv's output side
     flops = 2.0 * side.N * side.H * side.W * spec.cin * spec.cout * spec.k * spec.k
     name = f'igemm_halo_planes_kernel<{spec.k},s2,{"t" if d.transposed else "c"}>' if planes else \
-        _kname(_igemm_name(yv.C, as_fwd, prec, dzv.C), spec.k)
+        _kname(_igemm_name(yv.C, as_fwd, prec, dzv.C), spec.k, yv.C, yv.H)
     with _Prof(name, flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
 
@@ -694,7 +701,7 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     d.d_amax, keep1 = _amax_ptr(prec, da, dv)
     d.g_amax, keep2 = _amax_ptr(prec, ga, gv)
     if halo:
-        kname = (f'wgrad_pc_kernel<{spec.k},{"3" if spec.k == 3 else "2+2+1"},{_HTAG[prec]}>' if pc else
+        kname = (f'wgrad_pc_kernel<{spec.k},3,{"f16" if prec == "f16x3" else "bf16"}>' if pc else
                  f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else (1 if rows5 else "3+2")},{_HTAG[prec]}>')
     else:
         kname = ('wgrad_kernel' if prec == 'f32' else 'wgrad_split_kernel') + f'<{wcfg}{_KTAG[prec]}>'
