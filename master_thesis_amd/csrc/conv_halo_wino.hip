@@ -215,11 +215,25 @@ __global__ __launch_bounds__(512, 2) void igemm_wino16_kernel(ConvK p, int tiles
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm2 = wave >> 2, wn = wave & 3;
   const int li = lane & 31, lh = lane >> 5;
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  // 1-D grid over (pixel tile, n-tile).  Blocks are dealt round-robin over the 8 XCDs: the n-tiles of one
+  // pixel tile are consecutive blocks OF ONE XCD (they read the same halo: the second one is an L2 hit),
+  // and each XCD owns a contiguous band of pixel tiles (neighbouring halos overlap).
+  const int ntn = (p.Co + BN - 1) / BN, npt = p.N * tiles_y * tiles_x;      // (the grid is padded to 8 equal XCD shares)
+  const int lid = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+  int bid, nty;
+  {
+    const int q8 = npt >> 3, r8 = npt & 7;                   // tiles per XCD: q8 (+1 for the first r8 XCDs)
+    const int mine = q8 + (xcd < r8 ? 1 : 0), start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    // this XCD's blocks: lid = tile_local * ntn + n-tile; the grid is padded to 8 * ceil(...) blocks
+    const int tl = lid / ntn;
+    nty = lid - tl * ntn;
+    if (tl >= mine) return;
+    bid = start + tl;
+  }
   const int tx_ = bid % tiles_x; bid /= tiles_x;
   const int ty_ = bid % tiles_y;
   const int n = bid / tiles_y;
-  const int ty0 = ty_ * TH, tx0 = tx_ * TW, n0 = blockIdx.y * BN;
+  const int ty0 = ty_ * TH, tx0 = tx_ * TW, n0 = nty * BN;
   const int HL = p.H << p.ups, WL = p.W << p.ups;
   const float scA = FMT ? pow2_scale(*p.xamax) : 1.f;
   const float inv = FMT ? 1.f / (scA * pow2_scale(*p.wamax)) : 1.f;
@@ -276,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino16_kernel(ConvK p, int tiles
   const int nchunk = (p.C + CK - 1) / CK, ntile_w = (p.Co + BN - 1) / BN;
   bf16x8 fb[2][KSTEPS][NS];
   auto load_B = [&](bf16x8 (&f)[NS], int ch, int tap, int ks) {
-    const bf16x8* g = wfr + ((((long)tap * nchunk + ch) * ntile_w + blockIdx.y) * 4 + wn) * (KSTEPS * NS * 64) +
+    const bf16x8* g = wfr + ((((long)tap * nchunk + ch) * ntile_w + nty) * 4 + wn) * (KSTEPS * NS * 64) +
                       ks * NS * 64 + lane;
 #pragma unroll
     for (int s = 0; s < NS; ++s) f[s] = g[s * 64];
@@ -379,9 +393,11 @@ void mt_halo_wino_launch(const void* kp, int fmt, void* stream) {
   static const bool big = [] { const char* e = getenv("MT355_WINO16"); return !(e && e[0] == '0'); }();
   if (k.Co > 64 && big && k.Ho > 8) {          // 16 x 16 tiles (an 8-row image would waste half of one)
     const int ty16 = (k.Ho + 15) / 16;
-    const unsigned nt16 = (unsigned)k.N * ty16 * tiles_x;
-    if (fmt) hipLaunchKernelGGL((igemm_wino16_kernel<1>), dim3(nt16, (k.Co + 127) / 128), dim3(512), 0, s, k, ty16, tiles_x);
-    else hipLaunchKernelGGL((igemm_wino16_kernel<0>), dim3(nt16, (k.Co + 127) / 128), dim3(512), 0, s, k, ty16, tiles_x);
+    const unsigned nt16 = (unsigned)k.N * ty16 * tiles_x, ntn = (k.Co + 127) / 128;
+    // (padded so that every XCD gets the same number of block slots: gridDim.x / ntn must be the tile count)
+    const unsigned grid = 8 * ((nt16 + 7) / 8) * ntn;
+    if (fmt) hipLaunchKernelGGL((igemm_wino16_kernel<1>), dim3(grid), dim3(512), 0, s, k, ty16, tiles_x);
+    else hipLaunchKernelGGL((igemm_wino16_kernel<0>), dim3(grid), dim3(512), 0, s, k, ty16, tiles_x);
     return;
   }
   if (k.Co > 64) {

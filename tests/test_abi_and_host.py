@@ -112,3 +112,21 @@ def test_synthetic_batch_layout():
     fill = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1, 1)
     assert torch.equal(x, (1 - m) * y + m * fill)
     assert info[2].tolist() == [True, False] and float(info[4][1].abs().max()) == 0.0
+
+
+def test_bench_launcher_refuses_missing_gpus():
+    """`bench.py --gpus N` launches its own ranks; with fewer than N devices visible it must stop with
+    exit code 2 before anything else happens (here: no GPU at all), never report a 1-GPU number."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('needs a box with fewer than 2 GPUs')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and 'GPU(s) are visible' in r.stderr, (r.returncode, r.stderr[-300:])
+    # a rank whose launcher disagrees with --gpus stops too
+    env2 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env2, timeout=300)
+    assert r.returncode == 2 and 'launcher started 1 rank' in r.stderr, (r.returncode, r.stderr[-300:])
