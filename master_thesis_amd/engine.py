@@ -89,12 +89,15 @@ def halo_eligible(kind_fwd_like, stride, k, cin_p):
 HALO_RB = os.environ.get('MT355_HALO_RB', '1') != '0'     # mirrors halo_rb_wanted() in conv_halo.hip
 WGRAD_PC = os.environ.get('MT355_WGRAD_PC', '1') != '0'   # mirrors wgrad_pc() in conv_halo_wgrad.hip
 WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '512'))
+HALO_RB32 = os.environ.get('MT355_HALO_RB32', '0') == '1'  # mirrors halo_rb32_wanted() in conv_halo.hip (off by default)
 HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_enabled() in conv_halo_wino.hip
 
 
 def _igemm_name(co, halo, prec, cin_p=0):
     """Name of the kernel mt_conv_run picks (profiling labels only)."""
     cfg = '2,2,2,2' if co > 64 else ('2,2,2,1' if co > 32 else '4,1,1,1')
+    if halo and prec in ('f16x3', 'bf16x3') and cin_p > 32 and co <= 32 and HALO_RB32:
+        return 'igemm_halo_rb32_kernel<%s>|{k}' % ('f16' if prec == 'f16x3' else 'bf16')
     if halo and prec in ('f16x3', 'bf16x3') and cin_p > 32 and co > 32 and HALO_RB:
         # ('{k}' == 3: the 1-D Winograd F(2,3) variant; the caller substitutes k)
         return 'igemm_halo_{rbw}_kernel<{k},%s,%d>' % ('f16' if prec == 'f16x3' else 'bf16', 1 if co > 64 else 2)
@@ -107,6 +110,10 @@ def _igemm_name(co, halo, prec, cin_p=0):
 def _kname(template, k, co=0, ho=0):
     """Profiling label of a register-B shape: the Winograd kernels take the 3 x 3 layers
     (igemm_wino16_kernel: Cout > 64 and more than 8 output rows)."""
+    if '|{k}' in template:            # the 32-output-channel register-B kernel exists for 3 x 3 only
+        if k == 3:
+            return template.split('|')[0]
+        return 'igemm_halo_kernel<%d,%s,4,1,1,1>' % (k, '2,f16' if 'f16>' in template and 'bf16' not in template else '2,bf16')
     if k == 3 and HALO_WINO and '{rbw}' in template:
         fmt = 'f16' if ',f16' in template else 'bf16'
         if co > 64 and ho > 8:
