@@ -237,8 +237,9 @@ typedef struct {
 /* Layout mt_weight_pack_halo writes for this shape: 0 = LDS tile images, 1 = MFMA-fragment
  * order (the register-B kernel), 2 = fragment order of the 1-D Winograd F(2,3) transformed
  * weights G g (3 x 3 layers, T = 9: 12 (kernel row, xi) "taps"), 3 = fragment order with one
- * 32-channel tile per n-tile (3 x 3 layers with > 32 input and <= 32 output channels); the
- * kernels choose by the same rule. */
+ * 32-channel tile per n-tile (3 x 3 layers with > 32 input and <= 32 output channels), 4 = the
+ * Winograd weights as v_mfma_f32_16x16x32 fragments (128-wide tiles); the kernels choose by the
+ * same rule. */
 int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, int32_t T, int32_t precision);
 /* jobs_dev: njobs entries in device memory; equivalent to calling the single-pack
  * entry point of every job.  jobs_host: the same table in host memory (argument checks). */

@@ -497,6 +497,7 @@ bool halo_rb_wanted(int cin_p, int cout_p) {
 
 }  // namespace
 bool halo_wino_enabled();                                            // conv_halo_wino.hip
+bool halo_wino_mf16();
 void mt_halo_wino_launch(const void* convk, int fmt, void* stream);
 namespace {
 // 1-D Winograd F(2,3) on the 3 x 3 layers the register-B kernel would take (T = 9 taps)
@@ -635,8 +636,9 @@ __device__ __forceinline__ void pack_halo_rb_body(const float* src, int A, int B
 }
 
 __global__ void weight_pack_halo_wino_kernel(const float* src, int A, int B, long sa, long sb, long st, __bf16* dst, int nchunk,
-                                             int ntile, int flip, const float* wamax, int nchunk_total, int ch_off, int WN) {
-  pack_halo_wino_body(src, A, B, sa, sb, st, dst, nchunk, ntile, flip, wamax, nchunk_total, ch_off, WN);
+                                             int ntile, int flip, const float* wamax, int nchunk_total, int ch_off, int WN,
+                                             int mf16) {
+  pack_halo_wino_body(src, A, B, sa, sb, st, dst, nchunk, ntile, flip, wamax, nchunk_total, ch_off, WN, mf16);
 }
 
 __global__ void weight_pack_halo_rb_kernel(const float* src, int A, int B, int T, long sa, long sb, long st, __bf16* dst,
@@ -665,8 +667,9 @@ __global__ void weight_pack_jobs_kernel(const mt_pack_job* jobs) {
   const int BN = j.AP > 64 ? 128 : (j.AP > 32 ? 64 : 32);
   const int nchunk = (j.BP + CK - 1) / CK, ntile = (j.AP + BN - 1) / BN;
   const int nchunk_total = (j.BP_total + CK - 1) / CK, ch_off = j.b_off / CK;
-  if (j.frag_order == 2)
-    pack_halo_wino_body(j.src, j.A, j.B, j.sa, j.sb, j.st, dst, nchunk, ntile, j.flip, j.w_amax, nchunk_total, ch_off, BN / 32);
+  if (j.frag_order == 2 || j.frag_order == 4)
+    pack_halo_wino_body(j.src, j.A, j.B, j.sa, j.sb, j.st, dst, nchunk, ntile, j.flip, j.w_amax, nchunk_total, ch_off, BN / 32,
+                        j.frag_order == 4);
   else if (j.frag_order)
     pack_halo_rb_body(j.src, j.A, j.B, j.T, j.sa, j.sb, j.st, dst, nchunk, ntile, j.flip, j.w_amax, nchunk_total, ch_off,
                       BN / 32);
@@ -709,7 +712,8 @@ static int pack_halo_impl(const float* src, int32_t A, int32_t B, int32_t T, int
     const long tot = (long)12 * nchunk * ntile * (BN / 32) * 1024;
     hipLaunchKernelGGL(weight_pack_halo_wino_kernel, dim3(mt_grid_1d(tot, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), src, A, B, (long)sa, (long)sb, (long)st,
-                       reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, w_amax, nchunk_total, ch_off, BN / 32);
+                       reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, w_amax, nchunk_total, ch_off, BN / 32,
+                       (BN == 128 && halo_wino_mf16()) ? 1 : 0);
     return mt_check_launch("mt_weight_pack_halo(wino)");
   }
   if (NS == 2 && (halo_rb_wanted(BP_total, AP) || halo_rb32_wanted(BP_total, AP, T))) {     // fragment order for igemm_halo_rb(32)_kernel (fits the same buffer)
@@ -743,7 +747,8 @@ extern "C" int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, 
   if (precision == MT_PREC_BF16X6) return 0;
   if (halo_rb32_wanted(BP_total, AP, T)) return 3;
   if (!halo_rb_wanted(BP_total, AP)) return 0;
-  return halo_wino_wanted(BP_total, AP, T) ? 2 : 1;
+  if (!halo_wino_wanted(BP_total, AP, T)) return 1;
+  return (AP > 64 && halo_wino_mf16()) ? 4 : 2;        // 4: Winograd fragments of v_mfma_f32_16x16x32 (128-wide tiles)
 }
 
 extern "C" int mt_absmax_segments(const mt_amax_seg* segs_dev, int32_t nseg, void* stream) {
