@@ -59,6 +59,14 @@ CONV_CASES = [
     (1, 11, 30, 128, 64, 3, 1, 'c', 2),
     (1, 9, 7, 128, 128, 3, 2, 't', 0),
     (1, 19, 23, 64, 128, 5, 2, 'c', 1),
+    # round 2: the 8 x 16-tile Winograd kernel for 128-wide tiles (images of <= 8 rows), 256-channel n-tiles on
+    # ragged 16 x 16 tiles, the planes kernel with 64-wide tiles (strided and transposed gathers, odd sizes)
+    (2, 8, 8, 128, 128, 3, 1, 'c', 1),
+    (1, 7, 20, 128, 256, 3, 1, 'c', 2),
+    (1, 27, 35, 256, 256, 3, 1, 'c', 1),
+    (2, 16, 16, 64, 64, 3, 2, 'c', 2),
+    (2, 9, 11, 64, 64, 3, 2, 't', 1),
+    (1, 13, 10, 64, 64, 5, 2, 't', 0),
 ]
 
 
