@@ -148,6 +148,25 @@ __global__ void sumpool_kernel(const float* x, long xn, long xh, long xw, float*
 }
 
 struct V3 { const float* p; long sn, sh, sw; };
+
+// Iteration of the element-wise kernels over an NHWC view: a thread keeps ONE channel quad (c) and walks pixels
+// with a block-wide stride -- the quotient / remainder chain per element (64-bit, four divisions) made these
+// kernels ALU-bound at ~1.1 TB/s.  Pixel -> (n, y, x) is only decoded for views whose pixels are not evenly
+// spaced (32-bit arithmetic).
+struct PxWalk {
+  int c, ppb, pl;           // channel offset in floats, pixels per block, this thread's pixel slot (-1: idle)
+  __device__ PxWalk(int C4) {
+    ppb = blockDim.x / C4;
+    const int q = threadIdx.x / C4;
+    c = ((int)threadIdx.x - q * C4) * 4;
+    pl = q < ppb ? q : -1;
+  }
+};
+__device__ __forceinline__ long px_off(long sn, long sh, long sw, int H, int W, unsigned p) {
+  if (sh == (long)W * sw && sn == (long)H * sh) return (long)p * sw;        // evenly spaced pixels
+  const unsigned r = p / (unsigned)W, xx = p - r * (unsigned)W, n = r / (unsigned)H, yy = r - n * (unsigned)H;
+  return (long)n * sn + (long)yy * sh + (long)xx * sw;
+}
 // wave maximum raised into a device scalar (values >= 0 order like their bit patterns; the plain
 // read filters out almost every wave once the scalar is near its final value)
 __device__ __forceinline__ void wave_raise_amax(float v, float* out) {
@@ -159,37 +178,29 @@ __device__ __forceinline__ void wave_raise_amax(float v, float* out) {
 
 __global__ void axpby_kernel(V3 x, float a, V3 z, float b, float* y, long yn, long yh, long yw, int N, int H, int W,
                              int C4, float* yamax) {
-  const long total = (long)N * H * W * C4;
+  const PxWalk w(C4);
+  const unsigned P = (unsigned)N * H * W;
   float m = 0.f;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    int c = (int)(e % C4) * 4;
-    long r = e / C4;
-    int xx = (int)(r % W);
-    r /= W;
-    int yy = (int)(r % H);
-    int n = (int)(r / H);
-    f32x4 v = *reinterpret_cast<const f32x4*>(x.p + n * x.sn + yy * x.sh + xx * x.sw + c) * a;
-    if (z.p) v += *reinterpret_cast<const f32x4*>(z.p + n * z.sn + yy * z.sh + xx * z.sw + c) * b;
-    *reinterpret_cast<f32x4*>(y + n * yn + yy * yh + xx * yw + c) = v;
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-  }
+  if (w.pl >= 0)
+    for (unsigned p = blockIdx.x * w.ppb + w.pl; p < P; p += gridDim.x * w.ppb) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x.p + px_off(x.sn, x.sh, x.sw, H, W, p) + w.c) * a;
+      if (z.p) v += *reinterpret_cast<const f32x4*>(z.p + px_off(z.sn, z.sh, z.sw, H, W, p) + w.c) * b;
+      *reinterpret_cast<f32x4*>(y + px_off(yn, yh, yw, H, W, p) + w.c) = v;
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
   if (yamax) wave_raise_amax(m, yamax);
 }
 
 __global__ void dact_kernel(V3 x, V3 s, int act, float* y, long yn, long yh, long yw, int N, int H, int W, int C4) {
-  const long total = (long)N * H * W * C4;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    int c = (int)(e % C4) * 4;
-    long r = e / C4;
-    int xx = (int)(r % W);
-    r /= W;
-    int yy = (int)(r % H);
-    int n = (int)(r / H);
-    f32x4 v = *reinterpret_cast<const f32x4*>(x.p + n * x.sn + yy * x.sh + xx * x.sw + c);
-    f32x4 t = *reinterpret_cast<const f32x4*>(s.p + n * s.sn + yy * s.sh + xx * s.sw + c);
+  const PxWalk w(C4);
+  const unsigned P = (unsigned)N * H * W;
+  if (w.pl < 0) return;
+  for (unsigned p = blockIdx.x * w.ppb + w.pl; p < P; p += gridDim.x * w.ppb) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x.p + px_off(x.sn, x.sh, x.sw, H, W, p) + w.c);
+    const f32x4 t = *reinterpret_cast<const f32x4*>(s.p + px_off(s.sn, s.sh, s.sw, H, W, p) + w.c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] *= mt_dact_fn(t[j], act);
-    *reinterpret_cast<f32x4*>(y + n * yn + yy * yh + xx * yw + c) = v;
+    *reinterpret_cast<f32x4*>(y + px_off(yn, yh, yw, H, W, p) + w.c) = v;
   }
 }
 
@@ -539,18 +550,14 @@ __device__ __forceinline__ void block_amax(float v, float* out) {
 }
 
 __global__ void absmax_view_kernel(const float* x, long sn, long sh, long sw, int N, int H, int W, int C4, float* out) {
-  const long total = (long)N * H * W * C4;
+  const PxWalk w(C4);
+  const unsigned P = (unsigned)N * H * W;
   float m = 0.f;
-  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    int c = (int)(e % C4) * 4;
-    long r = e / C4;
-    int xx = (int)(r % W);
-    r /= W;
-    int yy = (int)(r % H);
-    int n = (int)(r / H);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + n * sn + yy * sh + xx * sw + c);
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-  }
+  if (w.pl >= 0)
+    for (unsigned p = blockIdx.x * w.ppb + w.pl; p < P; p += gridDim.x * w.ppb) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + px_off(sn, sh, sw, H, W, p) + w.c);
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
   block_amax(m, out);
 }
 
@@ -719,6 +726,7 @@ extern "C" int mt_axpby(const mt_view* x, float a, const mt_view* z, float b, co
                         void* stream) {
   MT_REQUIRE(mt_view_flat(x) && mt_view_flat(y) && same_geom(x, y) && x->C >= y->C, "mt_axpby: bad views");
   if (z && z->p) MT_REQUIRE(mt_view_flat(z) && same_geom(z, y) && z->C >= y->C, "mt_axpby: bad z view");
+  MT_REQUIRE(y->C <= 1024 && (int64_t)y->N * y->H * y->W < (1ll << 31), "mt_axpby: more than 1024 channels or 2^31 pixels");
   const long total = (long)y->N * y->H * y->W * (y->C / 4);
   hipLaunchKernelGGL(axpby_kernel, dim3(mt_grid_1d(total, 256)), dim3(256), 0, S_(stream), v3(x), a,
                      v3(z && z->p ? z : nullptr), b, y->p, (long)y->sn, (long)y->sh, (long)y->sw, y->N, y->H, y->W,
@@ -729,6 +737,7 @@ extern "C" int mt_axpby(const mt_view* x, float a, const mt_view* z, float b, co
 extern "C" int mt_dact(const mt_view* x, const mt_view* s, int32_t act, const mt_view* y, void* stream) {
   MT_REQUIRE(mt_view_flat(x) && mt_view_flat(s) && mt_view_flat(y) && same_geom(x, y) && same_geom(s, y) && x->C >= y->C &&
                  s->C >= y->C, "mt_dact: bad views");
+  MT_REQUIRE(y->C <= 1024 && (int64_t)y->N * y->H * y->W < (1ll << 31), "mt_dact: more than 1024 channels or 2^31 pixels");
   const long total = (long)y->N * y->H * y->W * (y->C / 4);
   hipLaunchKernelGGL(dact_kernel, dim3(mt_grid_1d(total, 256)), dim3(256), 0, S_(stream), v3(x), v3(s), act, y->p,
                      (long)y->sn, (long)y->sh, (long)y->sw, y->N, y->H, y->W, y->C / 4);
@@ -860,6 +869,7 @@ extern "C" int mt_adam_step_dev(float* p, const float* g, float* m, float* v, in
 
 extern "C" int mt_absmax(const mt_view* x, float* out, void* stream) {
   MT_REQUIRE(mt_view_flat(x) && out, "mt_absmax: bad arguments");
+  MT_REQUIRE(x->C <= 1024 && (int64_t)x->N * x->H * x->W < (1ll << 31), "mt_absmax: more than 1024 channels or 2^31 pixels");
   const long total = (long)x->N * x->H * x->W * (x->C / 4);
   hipLaunchKernelGGL(absmax_view_kernel, dim3(mt_grid_1d(total, 256, 2048)), dim3(256), 0, S_(stream), x->p,
                      (long)x->sn, (long)x->sh, (long)x->sw, x->N, x->H, x->W, x->C / 4, out);

@@ -134,7 +134,11 @@ class RRDBNetFn(torch.autograd.Function):
         # dz5 = (0.2 * s_rdb) * d_rdb
         _axpby(d_rdb, 0.2 * s_rdb, d_rdb, 0.0, dzb[..., :nf])
         if f16:
-            E.absmax_into(dzb[..., :nf], dba)
+            src_amax = getattr(d_rdb, '_mt_amax', None)
+            if src_amax is not None:     # d_rdb came out of a conv launch that recorded max|d_rdb|: scale it
+                torch.mul(src_amax, 0.2 * s_rdb, out=dba)
+            else:
+                E.absmax_into(dzb[..., :nf], dba)
         Bi = [None] + [P[f'{key}conv{i}.bias'] for i in (1, 2, 3, 4, 5)]
         dw, db = E.conv_backward_weight(spec(cw, nf), dzb[..., :nf], E.view_of(buf), W[5], x_amax=buf_amax, dz_amax=dba,
                                         grad_w=E.inplace_grad(W[5]), grad_b=E.inplace_grad(Bi[5]))
