@@ -255,10 +255,35 @@ __device__ __forceinline__ float pow2_scale(float amax) {
   return ldexpf(1.f, k);
 }
 
-template <int NS, int FMT>
+// SHADOW = 1: for code that runs beside MFMAs of the same SIMD (the staging waves of the producer /
+// consumer weight-gradient kernel).  Left to itself the compiler builds the split from v_pk_mul_f32
+// and v_fma_mixlo/hi_f16; packed-fp32, fma_mix*_f16 and dot2 instructions execute on the matrix
+// pipe's side of the SIMD and stall it -- measured (scratch/lab/coissue.hip): four of them per
+// MFMA, from the same or from another wave, cost 30-40 % of the MFMA rate, while v_mul_f32,
+// v_cvt_pk_f16_f32, v_cvt_f32_f16 and v_sub_f32 run in the MFMAs' shadow for free.  The shadow
+// form spends twice the instructions, so code that is NOT overlapped with MFMAs keeps SHADOW = 0.
+template <int NS, int FMT, int SHADOW = 0>
 __device__ __forceinline__ void split4f(const f32x4& v, float scale, bf16x4 (&out)[NS]) {
   if constexpr (FMT == 0) {
     split4<NS>(v, out);
+  } else if constexpr (SHADOW) {
+    static_assert(NS == 2, "f16x3 uses two fp16 terms");
+    unsigned hi[2], lo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float r0, r1, h0, h1, d0, d1;
+      asm("v_mul_f32 %0, %1, %2" : "=v"(r0) : "v"(v[2 * j]), "v"(scale));
+      asm("v_mul_f32 %0, %1, %2" : "=v"(r1) : "v"(v[2 * j + 1]), "v"(scale));
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi[j]) : "v"(r0), "v"(r1));
+      asm("v_cvt_f32_f16 %0, %1" : "=v"(h0) : "v"(hi[j]));
+      asm("v_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(h1) : "v"(hi[j]));
+      asm("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(r0), "v"(h0));
+      asm("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(r1), "v"(h1));
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo[j]) : "v"(d0), "v"(d1));
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    out[0] = __builtin_bit_cast(bf16x4, u32x2{hi[0], hi[1]});
+    out[1] = __builtin_bit_cast(bf16x4, u32x2{lo[0], lo[1]});
   } else {
     static_assert(NS == 2, "f16x3 uses two fp16 terms");
 #pragma unroll

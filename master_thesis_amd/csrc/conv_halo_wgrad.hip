@@ -1,6 +1,7 @@
 // Weight gradient of the stride-1 / stride-2 3x3 and 5x5 layers on LDS halo tiles (its own
 // translation unit: the template instantiations compile beside those of conv_halo.hip).
 #include <cstdlib>
+#include <type_traits>
 #include "conv_common.h"
 
 // ------------------------------------------------------------ wgrad (halo) --
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
 // buffer i & 1, waves 4-7 (their SIMD partners) load, split and store the NEXT pixel tile into the
 // other buffer -- VALU / LDS-write work that runs in the shadow of the partner's MFMAs.  One
 // barrier per pixel tile; 4 x 16-pixel tiles so that two images fit in LDS (2 x 49.5 KB, 3 x 3).
-template <int KS, int KHB, int FMT>
+template <int KS, int KHB, int FMT, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split, int ntiles,
                                                          int with_bias, int kh_base) {
   constexpr int NS = 2, TR = 4, TW = 16, PX = TR * TW, CH = 64, LD = CH + 8;
@@ -222,40 +223,76 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
   if (producer) {
     // ---- waves 4-7: global -> registers -> split -> LDS, one tile ahead of the consumers --------
     const int ptid = tid - 256;
-    f32x4 rd[RD], rg[RG];
-    auto load_tile = [&](int t) {
+    // two register sets: the loads of tiles i+2 and i+3 are in flight while tile i+1 is split and
+    // stored (one tile of look-ahead left the loads ~1 tile time to land: less than the loaded-memory
+    // latency, so the consumers waited at the barrier)
+    f32x4 rd[2][RD], rg[2][RG];
+    // Addressing: everything that depends on the tile (image, tile origin) is wave-uniform and
+    // lives in SGPRs; a thread adds 32-bit element offsets it computes once.  (64-bit per-load
+    // multiplies made the staging waves VALU-bound and kept the MFMA waves waiting at the barrier.)
+    // D: float4 idx = ptid + 256 i  ->  pixel row i, column ptid >> 4, channels 4 (ptid & 15)
+    const int rxD = ptid >> 4, c4 = (ptid & 15) * 4;
+    const bool chD = a0 + c4 < p.Cd, chG = b0 + c4 < p.Cg, ch_full = a0 + CH <= p.Cd && b0 + CH <= p.Cg;
+    const unsigned dsh = (unsigned)p.dsh, dsw = (unsigned)p.dsw, gsh = (unsigned)p.gsh, gsw = (unsigned)p.gsw;
+    const unsigned offD0 = rxD * dsw + a0 + c4;
+    unsigned offG[RG];          // patch pixel -> element offset from the patch origin (ups == 0)
+    int gyx[RG];                // patch pixel coordinates, gy << 8 | gx
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+      const int gpx = (ptid >> 4) + 16 * i, gy = gpx / GW, gx = gpx - gy * GW;
+      gyx[i] = gy << 8 | gx;
+      offG[i] = gy * gsh + gx * gsw + b0 + c4;
+    }
+    auto load_tile = [&](int t, auto set_c) {
+      constexpr int S = decltype(set_c)::value;
       const int tx = t % tiles_x, r = t / tiles_x, ty = r % tiles_y, n = r / tiles_y;
-      const int ty0 = ty * TR, tx0 = tx * TW;
-      const float* dp = p.d + (long)(n / p.dni) * p.dsg + (long)(n % p.dni) * p.dsn;
-      const float* gp = p.g + (long)(n / p.gni) * p.gsg + (long)(n % p.gni) * p.gsn;
+      const int ty0 = ty * TR, tx0 = tx * TW, gy0 = ty0 + kh0 - p.pad, gx0 = tx0 - p.pad;
+      const float* dimg = p.d + (long)(n / p.dni) * p.dsg + (long)(n % p.dni) * p.dsn;
+      const float* gimg = p.g + (long)(n / p.gni) * p.gsg + (long)(n % p.gni) * p.gsn;
+      const float* dp = dimg + (long)ty0 * p.dsh + (long)tx0 * p.dsw;
+      const bool inner = p.ups == 0 && ch_full && ty0 + TR <= p.Hd && tx0 + TW <= p.Wd && gy0 >= 0 && gy0 + GH <= HL &&
+                         gx0 >= 0 && gx0 + GW <= WL;
+      if (inner) {
+        const float* gp = gimg + (long)gy0 * p.gsh + (long)gx0 * p.gsw;
 #pragma unroll
-      for (int i = 0; i < RD; ++i) {
-        const int idx = ptid + 256 * i, px = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
-        const int y = ty0 + (px >> 4), x = tx0 + (px & 15);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (y < p.Hd && x < p.Wd && a0 + c < p.Cd)
-          v = *reinterpret_cast<const f32x4*>(dp + (long)y * p.dsh + (long)x * p.dsw + a0 + c);
-        rd[i] = v;
-      }
+        for (int i = 0; i < RD; ++i) rd[S][i] = *reinterpret_cast<const f32x4*>(dp + i * dsh + offD0);
 #pragma unroll
-      for (int i = 0; i < RG; ++i) {
-        const int idx = ptid + 256 * i, gpx = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
-        const int gy = gpx / GW, gx = gpx - gy * GW;
-        const int ly = ty0 + gy + kh0 - p.pad, lx = tx0 + gx - p.pad;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (idx < NG4 && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL && b0 + c < p.Cg)
-          v = *reinterpret_cast<const f32x4*>(gp + (long)(ly >> p.ups) * p.gsh + (long)(lx >> p.ups) * p.gsw + b0 + c);
-        rg[i] = v;
+        for (int i = 0; i < RG; ++i) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (ptid + 256 * i < NG4) v = *reinterpret_cast<const f32x4*>(gp + offG[i]);
+          rg[S][i] = v;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < RD; ++i) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (ty0 + i < p.Hd && tx0 + rxD < p.Wd && chD) v = *reinterpret_cast<const f32x4*>(dp + i * dsh + offD0);
+          rd[S][i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+          const int ly = gy0 + (gyx[i] >> 8), lx = gx0 + (gyx[i] & 255);
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (ptid + 256 * i < NG4 && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL && chG) {
+            const unsigned off = __umul24(ly >> p.ups, gsh) + __umul24(lx >> p.ups, gsw) + b0 + c4;
+            v = *reinterpret_cast<const f32x4*>(gimg + off);
+          }
+          rg[S][i] = v;
+        }
       }
     };
-    auto store_tile = [&](int buf) {
-      __bf16* sD = sm + buf * BUF_E;
+    // tile i lives in LDS buffer i & 1 and travels through register set i & 1
+    auto store_tile = [&](auto set_c) {
+      constexpr int S = decltype(set_c)::value;
+      __bf16* sD = sm + S * BUF_E;
       __bf16* sG = sD + D_E;
 #pragma unroll
       for (int i = 0; i < RD; ++i) {
         const int idx = ptid + 256 * i, px = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
         bf16x4 parts[NS];
-        split4f<NS, FMT>(rd[i], scD, parts);
+        if constexpr (ABL == 6) { parts[0] = __builtin_bit_cast(bf16x4, f32x2{rd[S][i][0], rd[S][i][1]}); parts[1] = __builtin_bit_cast(bf16x4, f32x2{rd[S][i][2], rd[S][i][3]}); }
+        else split4f<NS, FMT, 1>(rd[S][i], scD, parts);
+        if constexpr (ABL == 5) { asm volatile("" :: "v"(parts[0]), "v"(parts[1])); continue; }
 #pragma unroll
         for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sD[s * PX * LD + px * LD + c]) = parts[s];
       }
@@ -264,20 +301,46 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
         const int idx = ptid + 256 * i, gpx = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
         if (idx < NG4) {
           bf16x4 parts[NS];
-          split4f<NS, FMT>(rg[i], scG, parts);
+          if constexpr (ABL == 6) { parts[0] = __builtin_bit_cast(bf16x4, f32x2{rg[S][i][0], rg[S][i][1]}); parts[1] = __builtin_bit_cast(bf16x4, f32x2{rg[S][i][2], rg[S][i][3]}); }
+          else split4f<NS, FMT, 1>(rg[S][i], scG, parts);
+          if constexpr (ABL == 5) { asm volatile("" :: "v"(parts[0]), "v"(parts[1])); continue; }
 #pragma unroll
           for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sG[s * GP * LD + gpx * LD + c]) = parts[s];
         }
       }
     };
-    if (t_beg < t_end) { load_tile(t_beg); store_tile(0); }
-    if (t_beg + 1 < t_end) load_tile(t_beg + 1);
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    const int nt = t_end - t_beg;
+    if constexpr (ABL == 1) {
+      __syncthreads();
+      for (int i = 0; i < nt; ++i) __syncthreads();
+      return;
+    }
+    if constexpr (ABL == 4) {
+#pragma unroll
+      for (int i = 0; i < RD; ++i) { rd[0][i] = f32x4{1.f, 2.f, 3.f, 4.f}; rd[1][i] = rd[0][i]; }
+#pragma unroll
+      for (int i = 0; i < RG; ++i) { rg[0][i] = f32x4{1.f, 2.f, 3.f, 4.f}; rg[1][i] = rg[0][i]; }
+    }
+#define LOADT(t, S) do { if constexpr (ABL != 4) load_tile(t, S); } while (0)
+#define STORET(S) do { if constexpr (ABL != 3) store_tile(S); else { asm volatile("" :: "v"(rd[decltype(S)::value][0]), "v"(rg[decltype(S)::value][RG - 1]), "v"(rd[decltype(S)::value][RD - 1]), "v"(rg[decltype(S)::value][0])); } } while (0)
+    if (nt > 0) LOADT(t_beg, S0);
+    if (nt > 1) LOADT(t_beg + 1, S1);
+    if (nt > 0) STORET(S0);
+    if (nt > 2) LOADT(t_beg + 2, S0);
     __syncthreads();
-    for (int t = t_beg; t < t_end; ++t) {
-      if (t + 1 < t_end) store_tile((t + 1 - t_beg) & 1);
-      if (t + 2 < t_end) load_tile(t + 2);
+    for (int i = 0; i < nt; i += 2) {          // one barrier per tile, as in the consumer loop
+      if (i + 1 < nt) STORET(S1);
+      if (i + 3 < nt) LOADT(t_beg + i + 3, S1);
+      __syncthreads();
+      if (i + 1 >= nt) break;
+      if (i + 2 < nt) STORET(S0);
+      if (i + 4 < nt) LOADT(t_beg + i + 4, S0);
       __syncthreads();
     }
+#undef LOADT
+#undef STORET
     return;
   }
 
@@ -303,27 +366,39 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
   for (int t = t_beg; t < t_end; ++t) {
     const __bf16* sD = sm + ((t - t_beg) & 1) * BUF_E;
     const __bf16* sG = sD + D_E;
+    // Walk the PATCH rows: the G fragments of patch row r serve the pixel rows r, r-1, .. r-KHB+1
+    // (kernel rows 0 .. KHB-1), so each is read from LDS once per tile instead of KHB times, and the
+    // D fragments of the last KHB pixel rows stay in registers.  (Fragment reads were the bound of
+    // the pixel-row walk: 40 ds_read_b64_tr per 27 MFMAs and four waves on one LDS port.)
+    // (Requesting row r + 1 before the MFMAs of row r -- a fourth D slot and a second G set -- was
+    // measured and gained nothing: 1.87 vs 1.89 ms on the 256 x 256 x 128 x 128 layer.)
+    bf16x8 fa[KHB][NS];
 #pragma unroll
-    for (int ks = 0; ks < TR; ++ks) {
-      bf16x8 fa[NS];
+    for (int r = 0; r < GH; ++r) {
+      bf16x8 fb[KS][NS];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) fa[s] = tr_frag(sD + s * PX * LD, a_off + ks * 16 * LD, LD);
-      if (do_bias) {
+      for (int kw = 0; kw < KS; ++kw)
 #pragma unroll
-        for (int s = NS - 1; s >= 0; --s) {
-          if constexpr (FMT == 0) acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], ones, acc_bias, 0, 0, 0);
-          else acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[s]), __builtin_bit_cast(half8, ones), acc_bias, 0, 0, 0);
+        for (int s = 0; s < NS; ++s) fb[kw][s] = tr_frag(sG + s * GP * LD, b_off + (r * GW + kw) * LD, LD);
+      if (r < TR) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fa[r % KHB][s] = tr_frag(sD + s * PX * LD, a_off + r * 16 * LD, LD);
+        if (do_bias) {
+#pragma unroll
+          for (int s = NS - 1; s >= 0; --s) {
+            if constexpr (FMT == 0) acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[r % KHB][s], ones, acc_bias, 0, 0, 0);
+            else acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[r % KHB][s]), __builtin_bit_cast(half8, ones), acc_bias, 0, 0, 0);
+          }
         }
       }
 #pragma unroll
-      for (int kh = 0; kh < KHB; ++kh)
+      for (int kh = 0; kh < KHB; ++kh) {
+        const int ks = r - kh;                 // pixel row this patch row feeds through kernel row kh
+        if (ks >= 0 && ks < TR) {
 #pragma unroll
-        for (int kw = 0; kw < KS; ++kw) {
-          bf16x8 fb[NS];
-#pragma unroll
-          for (int s = 0; s < NS; ++s) fb[s] = tr_frag(sG + s * GP * LD, b_off + ((ks + kh) * GW + kw) * LD, LD);
-          mfma_splitf<NS, FMT>(fa, fb, acc[kh * KS + kw]);
+          for (int kw = 0; kw < KS; ++kw) mfma_splitf<NS, FMT>(fa[ks % KHB], fb[kw], acc[kh * KS + kw]);
         }
+      }
     }
     __syncthreads();
   }
@@ -394,7 +469,9 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   k.damax = d->d_amax; k.gamax = d->g_amax;
   k.skip = d->skip_tiles;
   // stride 1, two-term splits: the producer / consumer kernel (4-row tiles, two LDS images)
-  const bool pc = d->stride == 1 && prec != MT_PREC_BF16X6 && wgrad_pc() && d->KH == 3;   // (5 x 5: three launches lose to 3 + 2 rows)
+  const bool small_strides = d->d.sh < (1 << 24) && d->d.sw < (1 << 24) && d->g.sh < (1 << 24) && d->g.sw < (1 << 24) &&
+                             (long)d->d.H * d->d.sh < (1L << 31) && (long)d->g.H * d->g.sh < (1L << 31);   // 32-bit offsets inside an image
+  const bool pc = d->stride == 1 && prec != MT_PREC_BF16X6 && wgrad_pc() && d->KH == 3 && small_strides;   // (5 x 5: three launches lose to 3 + 2 rows)
   // 3x3 stride 1 (two-term splits): 8-row pixel tiles (measured: +6 %; the 5x5 gradient loses 3 % with them) (twice the MFMAs per staged tile and barrier)
   const bool tall = !pc && d->stride == 1 && d->KH == 3 && prec != MT_PREC_BF16X6 && wgrad3_tall();
   const int trows = tall ? 8 : 4;
@@ -408,8 +485,15 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
 #define MT_WGPC(KS, KHB, FMT, KH_BASE) \
   hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
+#define MT_WGPCA(A) \
+  hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, A>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0)
   if (pc) {
     const bool f16 = prec == MT_PREC_F16X3;
+    static const int abl = [] { const char* e = getenv("MT355_WGRAD_ABL"); return e ? atoi(e) : 0; }();
+    if (d->KH == 3 && f16 && abl) {
+      if (abl == 1) MT_WGPCA(1); else if (abl == 2) MT_WGPCA(2); else if (abl == 3) MT_WGPCA(3); else if (abl == 4) MT_WGPCA(4); else if (abl == 5) MT_WGPCA(5); else MT_WGPCA(6);
+      return 1;
+    }
     if (d->KH == 3) { if (f16) MT_WGPC(3, 3, 1, 0); else MT_WGPC(3, 3, 0, 0); }
     // 5 x 5: kernel rows {0,1} | {2,3} | {4} (15 accumulator tiles would not leave the MFMA waves
     // their operand registers at two waves per SIMD; the staging is off the critical path here)
