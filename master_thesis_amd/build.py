@@ -29,7 +29,9 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if force or _stale(obj, [path] + headers):
             cmds.append([hipcc, '-x', 'hip', '--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17',
-                         '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-c', path, '-o', obj] + extra)
+                         '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-c', path, '-o', obj] + extra +
+                        os.environ.get('MT355_CFLAGS', '').split() +                       # lab builds: extra flags for all /
+                        os.environ.get('MT355_CFLAGS_' + os.path.splitext(src)[0], '').split())   # one translation unit
     if cmds:      # the translation units compile side by side (conv_halo.hip alone is ~1.5 minutes)
         from concurrent.futures import ThreadPoolExecutor
 

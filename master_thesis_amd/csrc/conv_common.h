@@ -262,7 +262,10 @@ __device__ __forceinline__ float pow2_scale(float amax) {
 // MFMA, from the same or from another wave, cost 30-40 % of the MFMA rate, while v_mul_f32,
 // v_cvt_pk_f16_f32, v_cvt_f32_f16 and v_sub_f32 run in the MFMAs' shadow for free.  The shadow
 // form spends twice the instructions, so code that is NOT overlapped with MFMAs keeps SHADOW = 0.
-template <int NS, int FMT, int SHADOW = 0>
+#ifndef MT_SHADOW_DEFAULT
+#define MT_SHADOW_DEFAULT 0
+#endif
+template <int NS, int FMT, int SHADOW = MT_SHADOW_DEFAULT>
 __device__ __forceinline__ void split4f(const f32x4& v, float scale, bf16x4 (&out)[NS]) {
   if constexpr (FMT == 0) {
     split4<NS>(v, out);

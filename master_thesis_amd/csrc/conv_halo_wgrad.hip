@@ -54,40 +54,40 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
   const float scD = FMT ? pow2_scale(*p.damax) : 1.f, scG = FMT ? pow2_scale(*p.gamax) : 1.f;
   const float inv = 1.f / (scD * scG), inv_d = 1.f / scD;
 
-  // staging coordinates relative to the tile origin
-  int d_ry[RD], d_rx[RD], d_c[RD];
-#pragma unroll
-  for (int i = 0; i < RD; ++i) {
-    const int idx = tid + 256 * i, px = idx / (CH / 4);
-    d_c[i] = (idx % (CH / 4)) * 4; d_ry[i] = px >> 4; d_rx[i] = px & 15;
-  }
-  int g_y[RG], g_x[RG], g_c[RG];
+  // staging coordinates relative to the tile origin; the tile origin itself is wave-uniform, so a
+  // load address is (SGPR base) + (32-bit element offset): no per-load 64-bit multiplies
+  // D: float4 idx = tid + 256 i  ->  pixel row i, column tid >> 4, channels 4 (tid & 15)
+  const int rxD = tid >> 4, c4 = (tid & 15) * 4;
+  const bool chD = a0 + c4 < p.Cd, chG = b0 + c4 < p.Cg;
+  const unsigned dsh = (unsigned)p.dsh, dsw = (unsigned)p.dsw, gsh = (unsigned)p.gsh, gsw = (unsigned)p.gsw;
+  const unsigned offD0 = rxD * dsw + a0 + c4;
+  int gyx[RG];                // patch pixel coordinates, gy << 8 | gx
 #pragma unroll
   for (int i = 0; i < RG; ++i) {
-    const int idx = tid + 256 * i, gp = idx / (CH / 4);
-    g_c[i] = (idx % (CH / 4)) * 4; g_y[i] = gp / GW; g_x[i] = gp - g_y[i] * GW;
+    const int gpx = (tid >> 4) + 16 * i, gy = gpx / GW, gx = gpx - gy * GW;
+    gyx[i] = gy << 8 | gx;
   }
 
   f32x4 rd[RD], rg[RG];
   auto load_tile = [&](int t) {
     const int tx = t % tiles_x, r = t / tiles_x, ty = r % tiles_y, n = r / tiles_y;
-    const int ty0 = ty * TR, tx0 = tx * TW;
-    const float* dp = p.d + (long)(n / p.dni) * p.dsg + (long)(n % p.dni) * p.dsn;
-    const float* gp = p.g + (long)(n / p.gni) * p.gsg + (long)(n % p.gni) * p.gsn;
+    const int ty0 = ty * TR, tx0 = tx * TW, gy0 = ty0 * ST + kh0 - p.pad, gx0 = tx0 * ST - p.pad;
+    const float* dp = p.d + (long)(n / p.dni) * p.dsg + (long)(n % p.dni) * p.dsn + (long)ty0 * p.dsh + (long)tx0 * p.dsw;
+    const float* gimg = p.g + (long)(n / p.gni) * p.gsg + (long)(n % p.gni) * p.gsn;
 #pragma unroll
     for (int i = 0; i < RD; ++i) {
-      const int y = ty0 + d_ry[i], x = tx0 + d_rx[i];
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (y < p.Hd && x < p.Wd && a0 + d_c[i] < p.Cd)
-        v = *reinterpret_cast<const f32x4*>(dp + (long)y * p.dsh + (long)x * p.dsw + a0 + d_c[i]);
+      if (ty0 + i < p.Hd && tx0 + rxD < p.Wd && chD) v = *reinterpret_cast<const f32x4*>(dp + i * dsh + offD0);
       rd[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < RG; ++i) {
-      const int ly = ty0 * ST + g_y[i] + kh0 - p.pad, lx = tx0 * ST + g_x[i] - p.pad;
+      const int ly = gy0 + (gyx[i] >> 8), lx = gx0 + (gyx[i] & 255);
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (tid + 256 * i < NG4 && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL && b0 + g_c[i] < p.Cg)
-        v = *reinterpret_cast<const f32x4*>(gp + (long)(ly >> p.ups) * p.gsh + (long)(lx >> p.ups) * p.gsw + b0 + g_c[i]);
+      if (tid + 256 * i < NG4 && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL && chG) {
+        const unsigned off = __umul24(ly >> p.ups, gsh) + __umul24(lx >> p.ups, gsw) + b0 + c4;
+        v = *reinterpret_cast<const f32x4*>(gimg + off);
+      }
       rg[i] = v;
     }
   };
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
       split4f<NS, FMT>(rd[i], scD, parts);
       const int px = (tid + 256 * i) / (CH / 4);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sD[s][px * LD + d_c[i]]) = parts[s];
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sD[s][px * LD + c4]) = parts[s];
     }
 #pragma unroll
     for (int i = 0; i < RG; ++i) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
         split4f<NS, FMT>(rg[i], scG, parts);
         const int gp = (tid + 256 * i) / (CH / 4);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sG[s][gp * LD + g_c[i]]) = parts[s];
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sG[s][gp * LD + c4]) = parts[s];
       }
     }
   };
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
 // buffer i & 1, waves 4-7 (their SIMD partners) load, split and store the NEXT pixel tile into the
 // other buffer -- VALU / LDS-write work that runs in the shadow of the partner's MFMAs.  One
 // barrier per pixel tile; 4 x 16-pixel tiles so that two images fit in LDS (2 x 49.5 KB, 3 x 3).
-template <int KS, int KHB, int FMT, int ABL = 0>
+template <int KS, int KHB, int FMT>
 __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split, int ntiles,
                                                          int with_bias, int kh_base) {
   constexpr int NS = 2, TR = 4, TW = 16, PX = TR * TW, CH = 64, LD = CH + 8;
@@ -290,9 +290,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
       for (int i = 0; i < RD; ++i) {
         const int idx = ptid + 256 * i, px = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
         bf16x4 parts[NS];
-        if constexpr (ABL == 6) { parts[0] = __builtin_bit_cast(bf16x4, f32x2{rd[S][i][0], rd[S][i][1]}); parts[1] = __builtin_bit_cast(bf16x4, f32x2{rd[S][i][2], rd[S][i][3]}); }
-        else split4f<NS, FMT, 1>(rd[S][i], scD, parts);
-        if constexpr (ABL == 5) { asm volatile("" :: "v"(parts[0]), "v"(parts[1])); continue; }
+        split4f<NS, FMT, 1>(rd[S][i], scD, parts);
 #pragma unroll
         for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sD[s * PX * LD + px * LD + c]) = parts[s];
       }
@@ -301,9 +299,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
         const int idx = ptid + 256 * i, gpx = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
         if (idx < NG4) {
           bf16x4 parts[NS];
-          if constexpr (ABL == 6) { parts[0] = __builtin_bit_cast(bf16x4, f32x2{rg[S][i][0], rg[S][i][1]}); parts[1] = __builtin_bit_cast(bf16x4, f32x2{rg[S][i][2], rg[S][i][3]}); }
-          else split4f<NS, FMT, 1>(rg[S][i], scG, parts);
-          if constexpr (ABL == 5) { asm volatile("" :: "v"(parts[0]), "v"(parts[1])); continue; }
+          split4f<NS, FMT, 1>(rg[S][i], scG, parts);
 #pragma unroll
           for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sG[s * GP * LD + gpx * LD + c]) = parts[s];
         }
@@ -312,35 +308,20 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
     constexpr std::integral_constant<int, 0> S0{};
     constexpr std::integral_constant<int, 1> S1{};
     const int nt = t_end - t_beg;
-    if constexpr (ABL == 1) {
-      __syncthreads();
-      for (int i = 0; i < nt; ++i) __syncthreads();
-      return;
-    }
-    if constexpr (ABL == 4) {
-#pragma unroll
-      for (int i = 0; i < RD; ++i) { rd[0][i] = f32x4{1.f, 2.f, 3.f, 4.f}; rd[1][i] = rd[0][i]; }
-#pragma unroll
-      for (int i = 0; i < RG; ++i) { rg[0][i] = f32x4{1.f, 2.f, 3.f, 4.f}; rg[1][i] = rg[0][i]; }
-    }
-#define LOADT(t, S) do { if constexpr (ABL != 4) load_tile(t, S); } while (0)
-#define STORET(S) do { if constexpr (ABL != 3) store_tile(S); else { asm volatile("" :: "v"(rd[decltype(S)::value][0]), "v"(rg[decltype(S)::value][RG - 1]), "v"(rd[decltype(S)::value][RD - 1]), "v"(rg[decltype(S)::value][0])); } } while (0)
-    if (nt > 0) LOADT(t_beg, S0);
-    if (nt > 1) LOADT(t_beg + 1, S1);
-    if (nt > 0) STORET(S0);
-    if (nt > 2) LOADT(t_beg + 2, S0);
+    if (nt > 0) load_tile(t_beg, S0);
+    if (nt > 1) load_tile(t_beg + 1, S1);
+    if (nt > 0) store_tile(S0);
+    if (nt > 2) load_tile(t_beg + 2, S0);
     __syncthreads();
     for (int i = 0; i < nt; i += 2) {          // one barrier per tile, as in the consumer loop
-      if (i + 1 < nt) STORET(S1);
-      if (i + 3 < nt) LOADT(t_beg + i + 3, S1);
+      if (i + 1 < nt) store_tile(S1);
+      if (i + 3 < nt) load_tile(t_beg + i + 3, S1);
       __syncthreads();
       if (i + 1 >= nt) break;
-      if (i + 2 < nt) STORET(S0);
-      if (i + 4 < nt) LOADT(t_beg + i + 4, S0);
+      if (i + 2 < nt) store_tile(S0);
+      if (i + 4 < nt) load_tile(t_beg + i + 4, S0);
       __syncthreads();
     }
-#undef LOADT
-#undef STORET
     return;
   }
 
@@ -458,6 +439,9 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   if ((d->stride != 1 && d->stride != 2) || d->KH != d->KW || (d->KH != 3 && d->KH != 5) || d->pad != d->KH / 2) return 0;
   if (d->stride == 2 && (d->ups != 0 || prec == MT_PREC_BF16X6 || !wgrad_s2_halo())) return 0;
   if (prec == MT_PREC_F16X3 && (!d->d_amax || !d->g_amax)) return 0;
+  // 32-bit offsets inside an image (24-bit strides for v_mul_u32_u24): larger tensors take the generic kernel
+  if (!(d->d.sh < (1 << 24) && d->d.sw < (1 << 24) && d->g.sh < (1 << 24) && d->g.sw < (1 << 24) &&
+        (long)d->d.H * d->d.sh < (1L << 31) && (long)d->g.H * d->g.sh < (1L << 31))) return 0;
   WgK k;
   k.d = d->d.p; k.dsn = d->d.sn; k.dsh = d->d.sh; k.dsw = d->d.sw; k.Hd = d->d.H; k.Wd = d->d.W; k.Cd = d->d.C;
   k.g = d->g.p; k.gsn = d->g.sn; k.gsh = d->g.sh; k.gsw = d->g.sw; k.Hg = d->g.H; k.Wg = d->g.W; k.Cg = d->g.C;
@@ -469,9 +453,9 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   k.damax = d->d_amax; k.gamax = d->g_amax;
   k.skip = d->skip_tiles;
   // stride 1, two-term splits: the producer / consumer kernel (4-row tiles, two LDS images)
-  const bool small_strides = d->d.sh < (1 << 24) && d->d.sw < (1 << 24) && d->g.sh < (1 << 24) && d->g.sw < (1 << 24) &&
-                             (long)d->d.H * d->d.sh < (1L << 31) && (long)d->g.H * d->g.sh < (1L << 31);   // 32-bit offsets inside an image
-  const bool pc = d->stride == 1 && prec != MT_PREC_BF16X6 && wgrad_pc() && d->KH == 3 && small_strides;   // (5 x 5: three launches lose to 3 + 2 rows)
+  // 5 x 5: kernel rows {0,1} | {2,3} | {4} in three launches (MT355_WGRAD_PC5=0: the single-role kernel, rows {0,1,2} | {3,4})
+  static const bool pc5 = [] { const char* e = getenv("MT355_WGRAD_PC5"); return !(e && e[0] == '0'); }();
+  const bool pc = d->stride == 1 && prec != MT_PREC_BF16X6 && wgrad_pc() && (d->KH == 3 || pc5);
   // 3x3 stride 1 (two-term splits): 8-row pixel tiles (measured: +6 %; the 5x5 gradient loses 3 % with them) (twice the MFMAs per staged tile and barrier)
   const bool tall = !pc && d->stride == 1 && d->KH == 3 && prec != MT_PREC_BF16X6 && wgrad3_tall();
   const int trows = tall ? 8 : 4;
@@ -485,15 +469,8 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
 #define MT_WGPC(KS, KHB, FMT, KH_BASE) \
   hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
-#define MT_WGPCA(A) \
-  hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, A>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0)
   if (pc) {
     const bool f16 = prec == MT_PREC_F16X3;
-    static const int abl = [] { const char* e = getenv("MT355_WGRAD_ABL"); return e ? atoi(e) : 0; }();
-    if (d->KH == 3 && f16 && abl) {
-      if (abl == 1) MT_WGPCA(1); else if (abl == 2) MT_WGPCA(2); else if (abl == 3) MT_WGPCA(3); else if (abl == 4) MT_WGPCA(4); else if (abl == 5) MT_WGPCA(5); else MT_WGPCA(6);
-      return 1;
-    }
     if (d->KH == 3) { if (f16) MT_WGPC(3, 3, 1, 0); else MT_WGPC(3, 3, 0, 0); }
     // 5 x 5: kernel rows {0,1} | {2,3} | {4} (15 accumulator tiles would not leave the MFMA waves
     // their operand registers at two waves per SIMD; the staging is off the critical path here)

@@ -88,6 +88,7 @@ def halo_eligible(kind_fwd_like, stride, k, cin_p):
 
 HALO_RB = os.environ.get('MT355_HALO_RB', '1') != '0'     # mirrors halo_rb_wanted() in conv_halo.hip
 WGRAD_PC = os.environ.get('MT355_WGRAD_PC', '1') != '0'   # mirrors wgrad_pc() in conv_halo_wgrad.hip
+WGRAD_PC5 = os.environ.get('MT355_WGRAD_PC5', '1') != '0'  # 5x5 on the producer / consumer kernel too (kernel rows 2 + 2 + 1)
 WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '512'))
 HALO_RB32 = os.environ.get('MT355_HALO_RB32', '0') == '1'  # mirrors halo_rb32_wanted() in conv_halo.hip (off by default)
 HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_enabled() in conv_halo_wino.hip
@@ -679,7 +680,9 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
         rows5 = prec == 'bf16x6' or os.environ.get('MT355_WGRAD5_ROWS', '0') == '1'
         blocks = ((ap + 63) // 64) * ((bp + 63) // 64) * (1 if spec.k == 3 else (5 if rows5 else 2))
         # stride 1, two-term splits: the producer / consumer kernel (4-row tiles, 512-thread blocks, one per CU)
-        pc = spec.stride == 1 and prec != 'bf16x6' and WGRAD_PC and spec.k == 3
+        pc = spec.stride == 1 and prec != 'bf16x6' and WGRAD_PC and (spec.k == 3 or WGRAD_PC5)
+        if pc:
+            blocks = ((ap + 63) // 64) * ((bp + 63) // 64)       # (5 x 5: three launches of that many blocks x splits)
         # pixel tiles of 8 x 16 for the single-role 3x3 stride-1 gradient, 4 x 16 otherwise (as mt_wgrad_halo_try_launch)
         trows = 8 if (not pc and spec.k == 3 and spec.stride == 1 and prec != 'bf16x6'
                       and os.environ.get('MT355_WGRAD3_TALL', '1') != '0') else 4
@@ -708,7 +711,7 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     d.d_amax, keep1 = _amax_ptr(prec, da, dv)
     d.g_amax, keep2 = _amax_ptr(prec, ga, gv)
     if halo:
-        kname = (f'wgrad_pc_kernel<{spec.k},3,{"f16" if prec == "f16x3" else "bf16"}>' if pc else
+        kname = (f'wgrad_pc_kernel<{spec.k},{3 if spec.k == 3 else "2+2+1"},{"f16" if prec == "f16x3" else "bf16"}>' if pc else
                  f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else (1 if rows5 else "3+2")},{_HTAG[prec]}>')
     else:
         kname = ('wgrad_kernel' if prec == 'f32' else 'wgrad_split_kernel') + f'<{wcfg}{_KTAG[prec]}>'
