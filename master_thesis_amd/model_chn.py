@@ -110,7 +110,7 @@ class RRDBNetFn(torch.autograd.Function):
         return out, saved
 
     @staticmethod
-    def _rdb_backward_gather(key, P, G, buf, buf_amax, dzb, d_rdb, s_rdb, nf, gc, f16):
+    def _rdb_backward_gather(key, P, G, buf, buf_amax, dzb, dba, nf, gc, f16, nxt=None):
         """Backward of one ResidualDenseBlock5C (model_chn.py:602-623) in GATHER form.
 
         The layer-by-layer form scatters: the backward-data of conv_i adds into ALL the channels
@@ -120,25 +120,22 @@ class RRDBNetFn(torch.autograd.Function):
         so window i reads the channel PREFIX [dz5 .. dz(i+1)] against the stacked, tap-flipped
         weights [W5[:, win_i]; W4[:, win_i]; ...] and writes dz_i (gated by LeakyReLU'(buf[win_i]))
         right behind it; the last launch gives the block-input gradient with the residual path
-        fused (d_in = dense part + s_rdb * d_rdb).  Same MFMA work, every gradient channel is
-        written once, no accumulate passes.  Returns d_in."""
+        fused.  Same MFMA work, every gradient channel is written once, no accumulate passes.
+
+        The caller has put dz5 = 0.2 * e into dzb[..., :nf] (e = the gradient that reaches this
+        block's output, i.e. the residual path's share of d_in) with ``dba`` >= max|dz5|.  With
+        ``nxt = (window, amax)`` -- the dz5 window of the block that runs next in this backward --
+        the last launch writes 0.2 * d_in = 0.2 * dense + dz5 straight into it (and raises ``amax``):
+        no separate scale and max passes between the dense blocks of one RRDB.  Without ``nxt`` it
+        returns d_in = dense + 5 * dz5 (5 * fl(0.2 e) is e to one rounding)."""
         cw = nf + 4 * gc
         W = [None] + [P[f'{key}conv{i}.weight'] for i in (1, 2, 3, 4, 5)]
         prec = E.eff_precision(True)
         wa = E.stack_amax(W[1:]) if prec == 'f16x3' else None
-        dba = E.new_amax(buf.device) if f16 else None
 
         def spec(cin, cout):
             return E.LayerSpec('c', cin, cout, 3, 1, NONE, 0)
 
-        # dz5 = (0.2 * s_rdb) * d_rdb
-        _axpby(d_rdb, 0.2 * s_rdb, d_rdb, 0.0, dzb[..., :nf])
-        if f16:
-            src_amax = getattr(d_rdb, '_mt_amax', None)
-            if src_amax is not None:     # d_rdb came out of a conv launch that recorded max|d_rdb|: scale it
-                torch.mul(src_amax, 0.2 * s_rdb, out=dba)
-            else:
-                E.absmax_into(dzb[..., :nf], dba)
         Bi = [None] + [P[f'{key}conv{i}.bias'] for i in (1, 2, 3, 4, 5)]
         dw, db = E.conv_backward_weight(spec(cw, nf), dzb[..., :nf], E.view_of(buf), W[5], x_amax=buf_amax, dz_amax=dba,
                                         grad_w=E.inplace_grad(W[5]), grad_b=E.inplace_grad(Bi[5]))
@@ -150,10 +147,15 @@ class RRDBNetFn(torch.autograd.Function):
             E.conv_backward_data(spec(gc, kk), dzb[..., :kk], None, E.view_of(dzb[..., kk: kk + gc]),
                                  dsrc=buf[..., c0: c0 + gc], dact=LRELU, dz_amax=dba, y_amax=dba,
                                  packed=E.pack_stacked_bwd(srcs, c0, gc, prec, wa))
-        d_in = torch.empty(d_rdb.shape, device=d_rdb.device, dtype=torch.float32)
-        E.conv_backward_data(spec(nf, cw), dzb, None, E.view_of(d_in), dz_amax=dba,
-                             packed=E.pack_stacked_bwd([W[l] for l in (5, 4, 3, 2, 1)], 0, nf, prec, wa),
-                             res=d_rdb, beta=s_rdb)
+        packed_in = E.pack_stacked_bwd([W[l] for l in (5, 4, 3, 2, 1)], 0, nf, prec, wa)
+        if nxt is not None:
+            d_in = None
+            E.conv_backward_data(spec(nf, cw), dzb, None, E.view_of(nxt[0]), dz_amax=dba, packed=packed_in,
+                                 alpha=0.2, res=dzb[..., :nf], beta=1.0, y_amax=nxt[1])
+        else:
+            d_in = torch.empty(dzb.shape[:3] + (nf,), device=dzb.device, dtype=torch.float32)
+            E.conv_backward_data(spec(nf, cw), dzb, None, E.view_of(d_in), dz_amax=dba, packed=packed_in,
+                                 res=dzb[..., :nf], beta=5.0)
         # the four growth convs: one weight-gradient launch (dz4..dz1 are adjacent, conv_i reads buf[:c0_i])
         subs = [((4 - i) * gc, gc, nf + (i - 1) * gc, W[i], E.inplace_grad(W[i]), E.inplace_grad(Bi[i]))
                 for i in (1, 2, 3, 4)]
@@ -180,6 +182,8 @@ class RRDBNetFn(torch.autograd.Function):
         batched_wgrad = E.USE_HALO and E.PRECISION != 'f32' and os.environ.get('MT355_RDB_BATCHED_WGRAD', '1') != '0'
         # gather form of the dense-block backward (see _rdb_backward_gather); MT355_RDB_GATHER=0: layer by layer
         gather = batched_wgrad and os.environ.get('MT355_RDB_GATHER', '1') != '0'
+        # the launch that ends a dense block's backward writes the next block's dz5 window (MT355_RDB_FUSED_DZ5=0: separate passes)
+        fused_dz5 = os.environ.get('MT355_RDB_FUSED_DZ5', '1') != '0'
 
         def wgrad(key, sp, dz, xin, scale=1.0, x_amax=None, dz_amax=None):
             dw, db = E.conv_backward_weight(sp, dz, E.view_of(xin), P[key + '.weight'], scale=scale, x_amax=x_amax,
@@ -214,17 +218,35 @@ class RRDBNetFn(torch.autograd.Function):
         wgrad('trunk_conv', sp, dy, zbuf[..., :nf], x_amax=S['z_amax'])
         dcur = bdata('trunk_conv', sp, dy, torch.empty_like(dy))      # grad wrt the trunk output
         dbuf = torch.empty((n, h, w, cw), device=dy.device, dtype=torch.float32)
+        dbuf2 = torch.empty_like(dbuf) if gather else None    # the gather form alternates two gradient buffers
         bufs = S['bufs']
         for k in range(nb - 1, -1, -1):
             drr = dcur                                        # grad wrt this RRDB's output
             d_rdb, s_rdb = drr, 0.2                           # grad wrt rdb3's output = 0.2 * drr
+            if gather:
+                # rdb3: dz5 = 0.2 * (0.2 * drr); rdb2 / rdb1 get theirs from the launch that ends the block before
+                dzb, dzn = dbuf, dbuf2
+                dba = E.new_amax(dy.device) if f16 else None
+                _axpby(drr, 0.04, drr, 0.0, dzb[..., :nf])
+                if f16:
+                    E.absmax_into(dzb[..., :nf], dba)
+                for j in (3, 2, 1):
+                    key = f'rrdb_trunk.{k}.rdb{j}.'
+                    buf, buf_amax = bufs[3 * k + (j - 1)]
+                    nxt = (dzn[..., :nf], E.new_amax(dy.device) if f16 else None) if j > 1 and fused_dz5 else None
+                    d_rdb = RRDBNetFn._rdb_backward_gather(key, P, G, buf, buf_amax, dzb, dba, nf, gc, f16, nxt=nxt)
+                    if nxt is not None:
+                        dzb, dzn, dba = dzn, dzb, nxt[1]
+                    elif j > 1:          # (A/B path: separate scale and max passes)
+                        dba = E.new_amax(dy.device) if f16 else None
+                        _axpby(d_rdb, 0.2, d_rdb, 0.0, dzb[..., :nf])
+                        if f16:
+                            E.absmax_into(dzb[..., :nf], dba)
+                dcur = _axpby(d_rdb, 1.0, drr, 1.0, torch.empty_like(drr))
+                continue
             for j in (3, 2, 1):
                 key = f'rrdb_trunk.{k}.rdb{j}.'
                 buf, buf_amax = bufs[3 * k + (j - 1)]
-                if gather:
-                    d_rdb = RRDBNetFn._rdb_backward_gather(key, P, G, buf, buf_amax, dbuf, d_rdb, s_rdb, nf, gc, f16)
-                    s_rdb = 1.0
-                    continue
                 # running max|.| of what this block's launches write into dbuf (it bounds every window)
                 dba = E.new_amax(dy.device) if f16 else None
                 # out = 0.2 * conv5(cat) + x  with d(out) = s_rdb * d_rdb
