@@ -161,6 +161,13 @@ typedef struct {
 } mt_wgrad;
 
 int mt_wgrad_run(const mt_wgrad* d, void* stream);
+/* `n` weight gradients of identical geometry (everything but d.p, g.p, slabs, d_amax, g_amax) as ONE
+ * grid: stride-1 3x3 layers in MT_PREC_BF16X3 / MT_PREC_F16X3 only.  Each problem has its own slabs
+ * ([splits][...], reduced per problem with mt_wgrad_reduce / _multi).  For the dense blocks of the
+ * RRDBNet trunk (model_chn.py:588-623): their weight gradients do not depend on one another, so they
+ * run after the backward chain as one launch with few, long pixel ranges per block. */
+#define MT_WGRAD_BATCH_MAX 64
+int mt_wgrad_run_batch(const mt_wgrad* descs, int32_t n, void* stream);
 int64_t mt_wgrad_slab_floats(const mt_wgrad* d);
 /* dst[a*sa + b*sb + t*st] (+)= scale * sum_s slabs[s][a][t][b], a < A, b < B,
  * t < T; slabs are [splits][AP][TS][BP] with TS = T, or T + 1 when the launch

@@ -10,6 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmt355.so')
+WGRAD_BATCH_MAX = 64      # MT_WGRAD_BATCH_MAX (include/mt355.h)
 
 c_f32p = C.c_void_p
 i32, i64, f32 = C.c_int32, C.c_int64, C.c_float
@@ -78,6 +79,7 @@ SIGNATURES = {
     'mt_conv_run': [_P(Conv), _vp],
     'mt_conv_run_naive': [_P(Conv), _vp],
     'mt_wgrad_run': [_P(Wgrad), _vp],
+    'mt_wgrad_run_batch': [_vp, i32, _vp],
     'mt_wgrad_slab_floats': [_P(Wgrad)],
     'mt_wgrad_reduce': [_vp, i32, i32, i32, i32, i32, _vp, i32, i32, i64, i64, i64, i32, f32, _vp, _vp],
     'mt_wgrad_reduce_multi': [_vp, i32, i32, i32, i32, i32, _vp, i32, i32, f32, _vp],

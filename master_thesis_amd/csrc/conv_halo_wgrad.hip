@@ -194,9 +194,19 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
 // buffer i & 1, waves 4-7 (their SIMD partners) load, split and store the NEXT pixel tile into the
 // other buffer -- VALU / LDS-write work that runs in the shadow of the partner's MFMAs.  One
 // barrier per pixel tile; 4 x 16-pixel tiles so that two images fit in LDS (2 x 49.5 KB, 3 x 3).
-template <int KS, int KHB, int FMT>
+// BATCH: blockIdx.z selects one of up to MT_WGRAD_BATCH_MAX problems of identical geometry (the dense
+// blocks of an RRDB trunk: 60 weight gradients of 130 k pixels each run as one grid instead of 60
+// launches that each cut their pixels into ~100 slabs); their pointers travel in the kernel arguments.
+struct WgBatch {
+  const float* d[MT_WGRAD_BATCH_MAX]; const float* g[MT_WGRAD_BATCH_MAX]; float* slabs[MT_WGRAD_BATCH_MAX];
+  const float* damax[MT_WGRAD_BATCH_MAX]; const float* gamax[MT_WGRAD_BATCH_MAX];
+};
+struct WgOne {};
+
+template <int KS, int KHB, int FMT, bool BATCH = false>
 __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split, int ntiles,
-                                                         int with_bias, int kh_base) {
+                                                         int with_bias, int kh_base,
+                                                         std::conditional_t<BATCH, WgBatch, WgOne> tab) {
   constexpr int NS = 2, TR = 4, TW = 16, PX = TR * TW, CH = 64, LD = CH + 8;
   constexpr int GH = TR - 1 + KHB, GW = TW - 1 + KS, GP = GH * GW;
   constexpr int ND4 = PX * (CH / 4), RD = ND4 / 256;
@@ -215,9 +225,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
   if (at * p.btiles + bt < 32 && ((p.skip >> (at * p.btiles + bt)) & 1u)) return;   // tile nobody reads
   const int a0 = at * CH, b0 = bt * CH;
   const int split = blockIdx.y;
+  const float *pd, *pg, *pdamax, *pgamax;
+  float* pslabs;
+  if constexpr (BATCH) {
+    const int z = blockIdx.z;
+    pd = tab.d[z]; pg = tab.g[z]; pslabs = tab.slabs[z]; pdamax = tab.damax[z]; pgamax = tab.gamax[z];
+  } else {
+    pd = p.d; pg = p.g; pslabs = p.slabs; pdamax = p.damax; pgamax = p.gamax;
+  }
   const int t_beg = split * tiles_per_split, t_end = min(ntiles, t_beg + tiles_per_split);
   const int HL = p.Hg << p.ups, WL = p.Wg << p.ups;
-  const float scD = FMT ? pow2_scale(*p.damax) : 1.f, scG = FMT ? pow2_scale(*p.gamax) : 1.f;
+  const float scD = FMT ? pow2_scale(*pdamax) : 1.f, scG = FMT ? pow2_scale(*pgamax) : 1.f;
   const float inv = 1.f / (scD * scG), inv_d = 1.f / scD;
 
   if (producer) {
@@ -247,8 +265,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
       constexpr int S = decltype(set_c)::value;
       const int tx = t % tiles_x, r = t / tiles_x, ty = r % tiles_y, n = r / tiles_y;
       const int ty0 = ty * TR, tx0 = tx * TW, gy0 = ty0 + kh0 - p.pad, gx0 = tx0 - p.pad;
-      const float* dimg = p.d + (long)(n / p.dni) * p.dsg + (long)(n % p.dni) * p.dsn;
-      const float* gimg = p.g + (long)(n / p.gni) * p.gsg + (long)(n % p.gni) * p.gsn;
+      const float* dimg = pd + (long)(n / p.dni) * p.dsg + (long)(n % p.dni) * p.dsn;
+      const float* gimg = pg + (long)(n / p.gni) * p.gsg + (long)(n % p.gni) * p.gsn;
       const float* dp = dimg + (long)ty0 * p.dsh + (long)tx0 * p.dsw;
       const bool inner = p.ups == 0 && ch_full && ty0 + TR <= p.Hd && tx0 + TW <= p.Wd && gy0 >= 0 && gy0 + GH <= HL &&
                          gx0 >= 0 && gx0 + GW <= WL;
@@ -386,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
 
   const int T = p.KH * p.KW, li = lane & 31;
   const int TS = T + (with_bias ? 1 : 0);
-  float* slab = p.slabs + (long)split * p.Cd * TS * p.Cg;
+  float* slab = pslabs + (long)split * p.Cd * TS * p.Cg;
   if (do_bias && wn == 0 && li == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -468,7 +486,7 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
 #define MT_WGH2(KS, KHB, FMT, GRID, KH_BASE) \
   hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
 #define MT_WGPC(KS, KHB, FMT, KH_BASE) \
-  hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
+  hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{})
   if (pc) {
     const bool f16 = prec == MT_PREC_F16X3;
     if (d->KH == 3) { if (f16) MT_WGPC(3, 3, 1, 0); else MT_WGPC(3, 3, 0, 0); }
@@ -510,3 +528,55 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   return 1;
 }
 
+
+
+// Several weight gradients of IDENTICAL geometry as one grid (blockIdx.z = problem): 3 x 3, stride 1,
+// two-term split precisions, i.e. what the producer / consumer kernel takes.  The descriptors may
+// differ only in the tensor pointers, the slab pointer and the max|.| scalars.
+extern "C" int mt_wgrad_run_batch(const mt_wgrad* descs, int32_t n, void* stream) {
+  MT_REQUIRE(descs && n >= 1 && n <= MT_WGRAD_BATCH_MAX, "mt_wgrad_run_batch: 1..%d problems (got %d)", MT_WGRAD_BATCH_MAX, n);
+  const mt_wgrad* d = &descs[0];
+  const int prec = d->precision;
+  MT_REQUIRE(mt_view_ok(&d->d) && mt_view_ok(&d->g) && d->splits >= 1, "mt_wgrad_run_batch: invalid views / splits");
+  MT_REQUIRE(d->stride == 1 && d->KH == 3 && d->KW == 3 && d->pad == 1 && d->ups == 0 &&
+             (prec == MT_PREC_F16X3 || prec == MT_PREC_BF16X3) && d->algo == MT_ALGO_AUTO,
+             "mt_wgrad_run_batch: only stride-1 3x3 layers in BF16X3 / F16X3 (use mt_wgrad_run)");
+  MT_REQUIRE(d->d.N == d->g.N && d->d.H == d->g.H && d->d.W == d->g.W, "mt_wgrad_run_batch: D and G geometry differ");
+  MT_REQUIRE(d->d.sh < (1 << 24) && d->d.sw < (1 << 24) && d->g.sh < (1 << 24) && d->g.sw < (1 << 24) &&
+             (long)d->d.H * d->d.sh < (1L << 31) && (long)d->g.H * d->g.sh < (1L << 31), "mt_wgrad_run_batch: image too large for 32-bit offsets");
+  WgBatch tab;
+  for (int i = 0; i < n; ++i) {
+    const mt_wgrad* e = &descs[i];
+    const bool same = e->d.N == d->d.N && e->d.H == d->d.H && e->d.W == d->d.W && e->d.C == d->d.C && e->d.sn == d->d.sn &&
+                      e->d.sh == d->d.sh && e->d.sw == d->d.sw && e->d.n_in == d->d.n_in && e->d.sg == d->d.sg &&
+                      e->g.N == d->g.N && e->g.H == d->g.H && e->g.W == d->g.W && e->g.C == d->g.C && e->g.sn == d->g.sn &&
+                      e->g.sh == d->g.sh && e->g.sw == d->g.sw && e->g.n_in == d->g.n_in && e->g.sg == d->g.sg &&
+                      e->KH == d->KH && e->KW == d->KW && e->stride == d->stride && e->pad == d->pad && e->ups == d->ups &&
+                      e->splits == d->splits && e->precision == d->precision && e->algo == d->algo &&
+                      e->with_bias == d->with_bias && e->skip_tiles == d->skip_tiles;
+    MT_REQUIRE(same, "mt_wgrad_run_batch: problem %d differs from problem 0 in geometry", i);
+    MT_REQUIRE(e->d.p && e->g.p && e->slabs && (reinterpret_cast<uintptr_t>(e->d.p) & 15) == 0 && (reinterpret_cast<uintptr_t>(e->g.p) & 15) == 0,
+               "mt_wgrad_run_batch: problem %d: null / unaligned pointers", i);
+    MT_REQUIRE(prec != MT_PREC_F16X3 || (e->d_amax && e->g_amax), "mt_wgrad_run_batch: F16X3 needs d_amax and g_amax (problem %d)", i);
+    tab.d[i] = e->d.p; tab.g[i] = e->g.p; tab.slabs[i] = e->slabs; tab.damax[i] = e->d_amax; tab.gamax[i] = e->g_amax;
+  }
+  for (int i = n; i < MT_WGRAD_BATCH_MAX; ++i) { tab.d[i] = tab.g[i] = nullptr; tab.slabs[i] = nullptr; tab.damax[i] = tab.gamax[i] = nullptr; }
+  WgK k;
+  k.d = d->d.p; k.dsn = d->d.sn; k.dsh = d->d.sh; k.dsw = d->d.sw; k.Hd = d->d.H; k.Wd = d->d.W; k.Cd = d->d.C;
+  k.g = d->g.p; k.gsn = d->g.sn; k.gsh = d->g.sh; k.gsw = d->g.sw; k.Hg = d->g.H; k.Wg = d->g.W; k.Cg = d->g.C;
+  k.dni = d->d.n_in; k.dsg = d->d.sg; k.gni = d->g.n_in; k.gsg = d->g.sg;
+  k.KH = d->KH; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.ups = d->ups;
+  k.M = d->d.N * d->d.H * d->d.W; k.per_split = 0;
+  k.atiles = (k.Cd + 63) / 64; k.btiles = (k.Cg + 63) / 64;
+  k.slabs = d->slabs; k.damax = d->d_amax; k.gamax = d->g_amax; k.skip = d->skip_tiles;
+  const int tiles_y = (k.Hd + 3) / 4, tiles_x = (k.Wd + 15) / 16;
+  const int ntiles = d->d.N * tiles_y * tiles_x;
+  const int tps = (ntiles + d->splits - 1) / d->splits;
+  const dim3 grid(k.atiles * k.btiles, d->splits, n);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (prec == MT_PREC_F16X3)
+    hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, true>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
+  else
+    hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 0, true>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
+  return mt_check_launch("mt_wgrad_run_batch");
+}

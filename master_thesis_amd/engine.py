@@ -633,8 +633,48 @@ def inplace_grad(p):
     return None
 
 
+class WgradBatch:
+    """Weight gradients that do not depend on one another (the dense blocks of the RRDB trunk),
+    recorded during the backward chain and launched afterwards: one mt_wgrad_run_batch grid per
+    geometry (blockIdx.z = layer) instead of one launch per layer.  A single dense block has only
+    131 k pixels, so on its own it is cut into ~100 pixel ranges to fill the chip -- ~25 pixel
+    tiles per block, a 147 KB slab written per block and read back by the reduce; batched, every
+    block walks hundreds of tiles and the slabs shrink ~30x."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, d, keep, finish, blocks, ntiles, slab_floats, kname, flops):
+        key = (d.d.N, d.d.H, d.d.W, d.d.C, d.d.sn, d.d.sh, d.d.sw, d.d.n_in, d.d.sg, d.g.C, d.g.sn, d.g.sh, d.g.sw,
+               d.g.n_in, d.g.sg, d.precision, d.with_bias, d.skip_tiles)
+        self.items.append((key, d, keep, finish, blocks, ntiles, slab_floats, kname, flops))
+
+    def flush(self):
+        groups = {}
+        for it in self.items:
+            groups.setdefault(it[0], []).append(it)
+        self.items = []
+        for group in groups.values():
+            for c0 in range(0, len(group), L.WGRAD_BATCH_MAX):
+                chunk = group[c0: c0 + L.WGRAD_BATCH_MAX]
+                n = len(chunk)
+                _, d0, _, _, blocks, ntiles, per, kname, _ = chunk[0]
+                splits = max(1, min((WGRAD_PC_BLOCKS + blocks * n - 1) // (blocks * n), ntiles // 8 if ntiles >= 8 else 1, 256))
+                slabs = torch.empty((n * splits * per,), device=torch.device('cuda', torch.cuda.current_device()),
+                                    dtype=torch.float32)
+                arr = (L.Wgrad * n)()
+                for i, it in enumerate(chunk):
+                    it[1].splits = splits
+                    it[1].slabs = slabs.data_ptr() + 4 * i * splits * per
+                    C.memmove(C.byref(arr, i * C.sizeof(L.Wgrad)), C.byref(it[1]), C.sizeof(L.Wgrad))
+                with _Prof(kname + f' x{n}', sum(it[8] for it in chunk)):
+                    L.call('mt_wgrad_run_batch', arr, n, L.stream_ptr())
+                for i, it in enumerate(chunk):
+                    it[3](slabs[i * splits * per: (i + 1) * splits * per], splits)
+
+
 def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_amax=None, x_amax=None, sub_blocks=None,
-                         grad_w=None, grad_b=None):
+                         grad_w=None, grad_b=None, defer=None):
     """(dW, db) of one layer.  dz: (N,Ho,Wo,CoP) gradient wrt the layer's
     pre-activation output; xin_view: mt_view of the layer's input.
 
@@ -645,7 +685,12 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     every layer takes its sub-block of the slabs.  Returns [(dW_i, db_i), ...].
 
     ``grad_w`` / ``grad_b`` (sub_blocks: a 5th / 6th tuple entry): gradient buffers to ADD into
-    (see inplace_grad); the corresponding return value is then None."""
+    (see inplace_grad); the corresponding return value is then None.
+
+    ``defer``: a WgradBatch.  A layer the batched kernel takes (stride-1 3x3, two-term split) is
+    only recorded; WgradBatch.flush() launches it together with the others of its geometry and
+    fills the returned tensors then (dz, the input and the max|.| scalars must stay untouched
+    until the flush)."""
     dzv = view_of(dz)
     if spec.kind == 'c':
         dv, gv, a, b = dzv, xin_view, spec.cout, spec.cin
@@ -705,8 +750,6 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
                     need.add(at_ * nbt + bt_)
         d.skip_tiles = sum(1 << i for i in range(min(32, ((ap + 63) // 64) * nbt)) if i not in need)
     ts = t + (1 if fused_bias else 0)
-    slabs = torch.empty((d.splits * ap * ts * bp,), device=w.device, dtype=torch.float32)
-    d.slabs = slabs.data_ptr()
     d.precision = _PREC[prec]
     d.d_amax, keep1 = _amax_ptr(prec, da, dv)
     d.g_amax, keep2 = _amax_ptr(prec, ga, gv)
@@ -716,8 +759,14 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     else:
         kname = ('wgrad_kernel' if prec == 'f32' else 'wgrad_split_kernel') + f'<{wcfg}{_KTAG[prec]}>'
     useful = spec.cin * spec.cout if sub_blocks is None else sum(sb[1] * sb[2] for sb in sub_blocks)
-    with _Prof(kname, 2.0 * pixels * useful * t):     # (algorithmic FLOP: only the sub-blocks that are kept)
-        L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
+    flops = 2.0 * pixels * useful * t                 # (algorithmic FLOP: only the sub-blocks that are kept)
+    batchable = (defer is not None and halo and pc and spec.k == 3 and d.ups == 0 and prec in ('f16x3', 'bf16x3')
+                 and dv.H == gv.H and dv.W == gv.W)
+    if not batchable:
+        slabs = torch.empty((d.splits * ap * ts * bp,), device=w.device, dtype=torch.float32)
+        d.slabs = slabs.data_ptr()
+        with _Prof(kname, flops):
+            L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
     if sub_blocks is not None:
         assert spec.kind == 'c' and (fused_bias or not need_bias)
         outs, subs, keep = [], (L.ReduceSub * len(sub_blocks))(), []
@@ -735,15 +784,30 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
                                    dbi.data_ptr() if (fused_bias and dbi is not None) else None)
             outs.append((None, None) if inplace else (dwi, dbi))
         # every layer's sub-block (rows a0.. of every slab) in one reduce launch
-        L.call('mt_wgrad_reduce_multi', L.ptr(slabs), d.splits, ap, t, ts, bp, subs, len(sub_blocks),
-               1 if all_inplace else 0, scale, L.stream_ptr())
+        def finish(slabs_, splits_):
+            L.call('mt_wgrad_reduce_multi', L.ptr(slabs_), splits_, ap, t, ts, bp, subs, len(sub_blocks),
+                   1 if all_inplace else 0, scale, L.stream_ptr())
+        if batchable:
+            defer.add(d, (keep, keep1, keep2, dz, w), finish, blocks, ntiles, ap * ts * bp, kname, flops)
+        else:
+            finish(slabs, d.splits)
         return outs
     inplace = grad_w is not None and (grad_b is not None or not need_bias) and (fused_bias or not need_bias or scale == 1.0)
     dw = grad_w if inplace else torch.empty_like(w)
     db = (grad_b if inplace else torch.empty((spec.cout,), device=w.device, dtype=torch.float32)) if need_bias else None
     # both Conv2d (O,I,k,k) and ConvTranspose2d (I,O,k,k): a = dim 0, b = dim 1
-    L.call('mt_wgrad_reduce', L.ptr(slabs), d.splits, ap, t, ts, bp, L.ptr(dw), a, b, b * t, t, 1, 1 if inplace else 0, scale,
-           L.ptr(db) if fused_bias else None, L.stream_ptr())
+    def finish(slabs_, splits_):
+        L.call('mt_wgrad_reduce', L.ptr(slabs_), splits_, ap, t, ts, bp, L.ptr(dw), a, b, b * t, t, 1, 1 if inplace else 0, scale,
+               L.ptr(db) if fused_bias else None, L.stream_ptr())
+    if batchable and (fused_bias or not need_bias):
+        defer.add(d, (dw, db, keep1, keep2, dz, w), finish, blocks, ntiles, ap * ts * bp, kname, flops)
+        return (None, None) if inplace else (dw, db)
+    if batchable:       # (the separate bias pass below is not deferred: launch this one now)
+        slabs = torch.empty((d.splits * ap * ts * bp,), device=w.device, dtype=torch.float32)
+        d.slabs = slabs.data_ptr()
+        with _Prof(kname, flops):
+            L.call('mt_wgrad_run', C.byref(d), L.stream_ptr())
+    finish(slabs, d.splits)
     if need_bias and not fused_bias:
         ws = torch.empty((256 * dz.shape[3],), device=w.device, dtype=torch.float32)
         L.call('mt_bias_grad', C.byref(dzv), L.ptr(db), spec.cout, L.ptr(ws), 1 if inplace else 0, L.stream_ptr())

@@ -110,7 +110,7 @@ class RRDBNetFn(torch.autograd.Function):
         return out, saved
 
     @staticmethod
-    def _rdb_backward_gather(key, P, G, buf, buf_amax, dzb, dba, nf, gc, f16, nxt=None):
+    def _rdb_backward_gather(key, P, G, buf, buf_amax, dzb, dba, nf, gc, f16, nxt=None, defer=None):
         """Backward of one ResidualDenseBlock5C (model_chn.py:602-623) in GATHER form.
 
         The layer-by-layer form scatters: the backward-data of conv_i adds into ALL the channels
@@ -138,7 +138,7 @@ class RRDBNetFn(torch.autograd.Function):
 
         Bi = [None] + [P[f'{key}conv{i}.bias'] for i in (1, 2, 3, 4, 5)]
         dw, db = E.conv_backward_weight(spec(cw, nf), dzb[..., :nf], E.view_of(buf), W[5], x_amax=buf_amax, dz_amax=dba,
-                                        grad_w=E.inplace_grad(W[5]), grad_b=E.inplace_grad(Bi[5]))
+                                        grad_w=E.inplace_grad(W[5]), grad_b=E.inplace_grad(Bi[5]), defer=defer)
         G[f'{key}conv5.weight'], G[f'{key}conv5.bias'] = dw, db
         for i in (4, 3, 2, 1):
             kk = nf + (4 - i) * gc                  # channels of [dz5 .. dz(i+1)]
@@ -160,7 +160,7 @@ class RRDBNetFn(torch.autograd.Function):
         subs = [((4 - i) * gc, gc, nf + (i - 1) * gc, W[i], E.inplace_grad(W[i]), E.inplace_grad(Bi[i]))
                 for i in (1, 2, 3, 4)]
         res = E.conv_backward_weight(spec(nf + 3 * gc, 4 * gc), dzb[..., nf: cw], E.view_of(buf[..., :nf + 3 * gc]), W[1],
-                                     x_amax=buf_amax, dz_amax=dba, sub_blocks=subs)
+                                     x_amax=buf_amax, dz_amax=dba, sub_blocks=subs, defer=defer)
         for i, (dwi, dbi) in zip((1, 2, 3, 4), res):
             G[f'{key}conv{i}.weight'], G[f'{key}conv{i}.bias'] = dwi, dbi
         return d_in
@@ -219,12 +219,18 @@ class RRDBNetFn(torch.autograd.Function):
         dcur = bdata('trunk_conv', sp, dy, torch.empty_like(dy))      # grad wrt the trunk output
         dbuf = torch.empty((n, h, w, cw), device=dy.device, dtype=torch.float32)
         dbuf2 = torch.empty_like(dbuf) if gather else None    # the gather form alternates two gradient buffers
+        # The weight gradients of the dense blocks wait for the end of the chain and run as two batched
+        # launches (E.WgradBatch); every block then keeps its own gradient buffer until the flush
+        # (3 nb x 100 MB at B = 8, 256^2: the card has 288 GB).  MT355_RDB_WGRAD_BATCH=0: one launch per block.
+        wbatch = E.WgradBatch() if gather and os.environ.get('MT355_RDB_WGRAD_BATCH', '1') != '0' else None
         bufs = S['bufs']
         for k in range(nb - 1, -1, -1):
             drr = dcur                                        # grad wrt this RRDB's output
             d_rdb, s_rdb = drr, 0.2                           # grad wrt rdb3's output = 0.2 * drr
             if gather:
                 # rdb3: dz5 = 0.2 * (0.2 * drr); rdb2 / rdb1 get theirs from the launch that ends the block before
+                if wbatch is not None:
+                    dbuf, dbuf2 = torch.empty_like(dbuf), torch.empty_like(dbuf)
                 dzb, dzn = dbuf, dbuf2
                 dba = E.new_amax(dy.device) if f16 else None
                 _axpby(drr, 0.04, drr, 0.0, dzb[..., :nf])
@@ -234,10 +240,13 @@ class RRDBNetFn(torch.autograd.Function):
                     key = f'rrdb_trunk.{k}.rdb{j}.'
                     buf, buf_amax = bufs[3 * k + (j - 1)]
                     nxt = (dzn[..., :nf], E.new_amax(dy.device) if f16 else None) if j > 1 and fused_dz5 else None
-                    d_rdb = RRDBNetFn._rdb_backward_gather(key, P, G, buf, buf_amax, dzb, dba, nf, gc, f16, nxt=nxt)
+                    d_rdb = RRDBNetFn._rdb_backward_gather(key, P, G, buf, buf_amax, dzb, dba, nf, gc, f16, nxt=nxt,
+                                                           defer=wbatch)
                     if nxt is not None:
-                        dzb, dzn, dba = dzn, dzb, nxt[1]
+                        dzb, dzn, dba = dzn, (torch.empty_like(dzb) if wbatch is not None else dzb), nxt[1]
                     elif j > 1:          # (A/B path: separate scale and max passes)
+                        if wbatch is not None:
+                            dzb = torch.empty_like(dzb)
                         dba = E.new_amax(dy.device) if f16 else None
                         _axpby(d_rdb, 0.2, d_rdb, 0.0, dzb[..., :nf])
                         if f16:
@@ -279,6 +288,8 @@ class RRDBNetFn(torch.autograd.Function):
                 d_rdb, s_rdb = d_in, 1.0
             # RRDB: out = 0.2 * y3 + x  ->  d(x) = d(rdb1 input) + drr
             dcur = _axpby(d_rdb, 1.0, drr, 1.0, torch.empty_like(drr))
+        if wbatch is not None:
+            wbatch.flush()
         df0 = _axpby(dcur, 1.0, dy, 1.0, torch.empty_like(dy))
         first = S['first']
         dz = df0
