@@ -2,6 +2,11 @@
 // translation unit: the template instantiations compile beside those of conv_halo.hip).
 #include <cstdlib>
 #include <type_traits>
+// LDS row padding (16-bit elements) of the producer / consumer kernel: rows of 96 put the four pixel rows of a
+// transposed fragment read on banks 0 / 48 / 32 / 16 (72: two of them share 8 banks); +1 % (3x3), +4 % (5x5)
+#ifndef MT_WGPC_PAD
+#define MT_WGPC_PAD 32
+#endif
 #include "conv_common.h"
 
 // ------------------------------------------------------------ wgrad (halo) --
@@ -207,7 +212,7 @@ template <int KS, int KHB, int FMT, bool BATCH = false>
 __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split, int ntiles,
                                                          int with_bias, int kh_base,
                                                          std::conditional_t<BATCH, WgBatch, WgOne> tab) {
-  constexpr int NS = 2, TR = 4, TW = 16, PX = TR * TW, CH = 64, LD = CH + 8;
+  constexpr int NS = 2, TR = 4, TW = 16, PX = TR * TW, CH = 64, LD = CH + MT_WGPC_PAD;
   constexpr int GH = TR - 1 + KHB, GW = TW - 1 + KS, GP = GH * GW;
   constexpr int ND4 = PX * (CH / 4), RD = ND4 / 256;
   constexpr int NG4 = GP * (CH / 4), RG = (NG4 + 255) / 256;
