@@ -132,6 +132,17 @@ typedef struct {
 } mt_conv;
 
 int mt_conv_run(const mt_conv* d, void* stream);
+/* The same call for stride-1 3x3 "same" layers whose gathered tensor has at most FOUR real channels and whose
+ * output has 64 or 128 (model_vgg.py:40 conv1_1, the 1 -> 128 entry of SeparableConv4d model_dfpn.py:596-605,
+ * and the backward-data of the 128 -> 1 / 128 -> 2 exits, model_dfpn.py:604,710): plain fp32 on the VALU, no
+ * operand split and no packed weights -- the launch is bound by the tensor it writes.  `w` are the parameter's
+ * own fp32 weights, addressed as w[co * so + ci * si + tap * st] (tap = kh * 3 + kw); flip = 1 reverses the
+ * taps (a Conv2d's backward-data run as a forward convolution, with the two channel strides swapped).
+ * Supported of mt_conv: x / y views (two-level image index included), bias, act, alpha, dsrc / dact
+ * (dact_c0 = 0), y_amax.  wt, wt_layout, precision, x_amax, w_amax are ignored; res / accumulate / ups /
+ * transposed must be off. */
+int mt_conv_tiny_in_run(const mt_conv* d, const float* w, int32_t cin, int64_t so, int64_t si, int64_t st,
+                        int32_t flip, void* stream);
 /* slow one-thread-per-output restatement of mt_conv_run (self-check only) */
 int mt_conv_run_naive(const mt_conv* d, void* stream);
 
@@ -166,6 +177,11 @@ int mt_wgrad_run(const mt_wgrad* d, void* stream);
  * ([splits][...], reduced per problem with mt_wgrad_reduce / _multi).  For the dense blocks of the
  * RRDBNet trunk (model_chn.py:588-623): their weight gradients do not depend on one another, so they
  * run after the backward chain as one launch with few, long pixel ranges per block. */
+/* The weight (+ bias) gradient of a stride-1 3x3 "same" Conv2d with `tiny` <= 4 real channels on one side and 64 or
+ * 128 on the other (the layers mt_conv_tiny_in_run serves, and the 128 -> 1 / 128 -> 2 exits): fp32 on the VALU,
+ * the wide tensor is read once.  d->splits blocks each write one slab in mt_wgrad_run's layout; reduce as usual.
+ * precision, d_amax, g_amax are ignored; skip_tiles must be 0. */
+int mt_wgrad_tiny_run(const mt_wgrad* d, int32_t tiny, void* stream);
 #define MT_WGRAD_BATCH_MAX 64
 int mt_wgrad_run_batch(const mt_wgrad* descs, int32_t n, void* stream);
 int64_t mt_wgrad_slab_floats(const mt_wgrad* d);

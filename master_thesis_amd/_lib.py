@@ -78,8 +78,10 @@ SIGNATURES = {
     'mt_last_error': [],
     'mt_conv_run': [_P(Conv), _vp],
     'mt_conv_run_naive': [_P(Conv), _vp],
+    'mt_conv_tiny_in_run': [_P(Conv), _vp, i32, i64, i64, i64, i32, _vp],
     'mt_wgrad_run': [_P(Wgrad), _vp],
     'mt_wgrad_run_batch': [_vp, i32, _vp],
+    'mt_wgrad_tiny_run': [_P(Wgrad), i32, _vp],
     'mt_wgrad_slab_floats': [_P(Wgrad)],
     'mt_wgrad_reduce': [_vp, i32, i32, i32, i32, i32, _vp, i32, i32, i64, i64, i64, i32, f32, _vp, _vp],
     'mt_wgrad_reduce_multi': [_vp, i32, i32, i32, i32, i32, _vp, i32, i32, f32, _vp],

@@ -92,6 +92,13 @@ WGRAD_PC5 = os.environ.get('MT355_WGRAD_PC5', '1') != '0'  # 5x5 on the producer
 WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '512'))
 HALO_RB32 = os.environ.get('MT355_HALO_RB32', '0') == '1'  # mirrors halo_rb32_wanted() in conv_halo.hip (off by default)
 HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_enabled() in conv_halo_wino.hip
+TINY = os.environ.get('MT355_TINY', '1') != '0'           # fp32 VALU kernels for layers with <= 4 channels on one side (conv_tiny.hip)
+
+
+def tiny_in_eligible(kind_c, stride, k, pad, ups, cin_real, cout_real, x_cp):
+    """mt_conv_tiny_in_run takes the layer: stride-1 3x3 'same', <= 4 real gathered channels, 64 / 128 outputs."""
+    return (TINY and USE_HALO and kind_c and stride == 1 and k == 3 and pad == 1 and ups == 0 and 1 <= cin_real <= 4
+            and cout_real in (64, 128) and x_cp >= 4)
 
 
 def _igemm_name(co, halo, prec, cin_p=0):
@@ -534,6 +541,18 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
     d.x, d.y = xv, view_of(out)
     halo = halo_eligible(spec.kind == 'c', spec.stride, spec.k, xv.C)
     prec = eff_precision(halo)
+    if (res is None and w.is_contiguous() and out.shape[3] == spec.cout
+            and tiny_in_eligible(spec.kind == 'c', spec.stride, spec.k, spec.pad, spec.ups, spec.cin, spec.cout, xv.C)):
+        pb = _pad_bias(b, spec.cout)
+        d.bias = pb.data_ptr() if pb is not None else None
+        d.KH = d.KW = 3
+        d.stride, d.pad, d.ups, d.transposed = 1, 1, 0, 0
+        d.act, d.alpha, d.beta = spec.act, alpha, 0.0
+        d.res, d.dsrc = null_view(), null_view()
+        d.y_amax, keep_y = _out_amax(prec, y_amax, out)
+        with _Prof('conv_tiny_in_kernel', 2.0 * n * ho * wo * spec.cin * spec.cout * 9):
+            L.call('mt_conv_tiny_in_run', C.byref(d), L.ptr(w), spec.cin, spec.cin * 9, 9, 1, 0, L.stream_ptr())
+        return out
     transposed = 0 if spec.kind == 'c' else 1
     planes = planes_eligible(spec.stride, spec.k, xv.C, out.shape[3], prec, spec.ups)
     packed, wa = _pack(w, 0 if spec.kind == 'c' else 1, 'f', prec, halo=halo, planes=transposed if planes else None)
@@ -577,6 +596,21 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     # conv so that it takes the halo-tile kernel
     as_fwd = halo_eligible(spec.kind == 'c', spec.stride, spec.k, dz.shape[3])
     prec = eff_precision(as_fwd)
+    if (packed is None and res is None and not accumulate and dact_c0 == 0 and w is not None and w.is_contiguous()
+            and yv.C == spec.cin
+            and tiny_in_eligible(spec.kind == 'c', spec.stride, spec.k, spec.pad, 0, spec.cout, spec.cin, dzv.C)):
+        # backward-data of a Conv2d with <= 4 output channels = a forward conv of dZ with the tap-reversed kernel
+        d.bias = None
+        d.KH = d.KW = 3
+        d.stride, d.pad, d.ups, d.transposed = 1, 1, 0, 0
+        d.act, d.alpha, d.beta = L.ACT_NONE, alpha, 0.0
+        d.res = null_view()
+        d.dsrc = view_of(dsrc) if dsrc is not None else null_view()
+        d.dact, d.dact_c0, d.accumulate = dact, 0, 0
+        d.y_amax, keep_y = _out_amax(prec, y_amax, yv._src)
+        with _Prof('conv_tiny_in_kernel', 2.0 * dzv.N * dzv.H * dzv.W * spec.cin * spec.cout * 9):
+            L.call('mt_conv_tiny_in_run', C.byref(d), L.ptr(w), spec.cout, 9, spec.cin * 9, 1, 1, L.stream_ptr())
+        return
     if packed is not None:      # a stacked image from pack_stacked_bwd (halo-tile kernels only)
         assert as_fwd
         packed, wa = packed
@@ -762,7 +796,21 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     flops = 2.0 * pixels * useful * t                 # (algorithmic FLOP: only the sub-blocks that are kept)
     batchable = (defer is not None and halo and pc and spec.k == 3 and d.ups == 0 and prec in ('f16x3', 'bf16x3')
                  and dv.H == gv.H and dv.W == gv.W)
-    if not batchable:
+    # <= 4 real channels on one side, 64 / 128 on the other, stride-1 3x3: the fp32 VALU kernel (conv_tiny.hip)
+    tiny_w = (TINY and halo and spec.kind == 'c' and spec.stride == 1 and spec.k == 3 and spec.pad == 1 and d.ups == 0
+              and sub_blocks is None and min(spec.cin, spec.cout) <= 4 and max(spec.cin, spec.cout) in (64, 128)
+              and max(ap, bp) == max(spec.cin, spec.cout) and dv.H == gv.H and dv.W == gv.W)
+    if tiny_w:
+        rows = 8 if max(ap, bp) == 128 else 16
+        nt_ = dv.N * ((dv.H + rows - 1) // rows) * ((dv.W + 15) // 16)
+        d.splits = max(1, min(512, nt_))
+        d.skip_tiles = 0
+        slabs = torch.empty((d.splits * ap * ts * bp,), device=w.device, dtype=torch.float32)
+        d.slabs = slabs.data_ptr()
+        with _Prof('wgrad_tiny_kernel', flops):
+            L.call('mt_wgrad_tiny_run', C.byref(d), min(spec.cin, spec.cout), L.stream_ptr())
+        batchable = False
+    elif not batchable:
         slabs = torch.empty((d.splits * ap * ts * bp,), device=w.device, dtype=torch.float32)
         d.slabs = slabs.data_ptr()
         with _Prof(kname, flops):

@@ -67,6 +67,11 @@ CONV_CASES = [
     (2, 16, 16, 64, 64, 3, 2, 'c', 2),
     (2, 9, 11, 64, 64, 3, 2, 't', 1),
     (1, 13, 10, 64, 64, 5, 2, 't', 0),
+    # the fp32 VALU kernels for layers with <= 4 channels on one side (ragged tiles, all three activations)
+    (2, 19, 27, 2, 128, 3, 1, 'c', 2),
+    (1, 21, 13, 3, 64, 3, 1, 'c', 1),
+    (2, 13, 9, 128, 1, 3, 1, 'c', 0),
+    (1, 17, 33, 64, 3, 3, 1, 'c', 1),
 ]
 
 
@@ -168,6 +173,31 @@ def test_conv3x3_f16x3_is_fp32_grade(mt, case):
     e_bwd = float((xg.grad.cpu().double() - x64.grad).abs().max() / x64.grad.abs().max())
     e_ref = float((y32.double() - y64.detach()).abs().max() / y64.detach().abs().max())
     assert e_fwd < 3e-6 and e_bwd < 3e-6, (e_fwd, e_bwd, e_ref)
+
+
+def test_tiny_exit_layer_gates_by_the_saved_activation(mt):
+    """conv(64 -> 128, ReLU) -> conv(128 -> 2): the backward-data of the 2-channel exit runs on the fp32 VALU
+    kernel and gates by ReLU'(saved output) in its epilogue (model_dfpn.py:708-710)."""
+    from master_thesis_amd import engine as E
+    from master_thesis_amd import _lib as L
+    specs = [E.LayerSpec('c', 64, 128, 3, 1, L.ACT_RELU), E.LayerSpec('c', 128, 2, 3, 1, L.ACT_NONE)]
+    shapes = [(128, 64, 3, 3), (128,), (2, 128, 3, 3), (2,)]
+    ps = [S.uniform(f'tinychain.p{i}', s, -0.1, 0.1) for i, s in enumerate(shapes)]
+    x = S.uniform('tinychain.x', (2, 64, 18, 22), -1, 1)
+    pr = [p.clone().requires_grad_(True) for p in ps]
+    xr = x.clone().requires_grad_(True)
+    y = F.conv2d(F.relu(F.conv2d(xr, pr[0], pr[1], padding=1)), pr[2], pr[3], padding=1)
+    gy = S.uniform('tinychain.gy', tuple(y.shape), -1, 1)
+    y.backward(gy)
+    xg = x.to(dev()).requires_grad_(True)
+    pg = [p.to(dev()).requires_grad_(True) for p in ps]
+    y4 = E.conv_stack(E.ToNHWC4Fn.apply(xg), specs, pg)
+    yd = E.FromNHWC4Fn.apply(y4, 2)
+    assert_close(yd, y, what='forward')
+    yd.backward(gy.to(dev()))
+    assert_close(xg.grad, xr.grad, what='bwd-data')
+    for a, b in zip(pg, pr):
+        assert_close(a.grad, b.grad, what='parameter gradient')
 
 
 def test_conv_stack_chain(mt, precision):
