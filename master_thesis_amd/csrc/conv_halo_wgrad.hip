@@ -429,6 +429,188 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
   }
 }
 
+
+// ---- 16 gathered channels (FlowEstimator's 10 -> 128 entry, RRDBNet's 9 -> 64 entry) ---------------------------
+// With G only 16 channels wide a 64-column B tile of the kernel above is three quarters padding, and a 5 x 5 layer
+// pays that for 25 taps in three launches.  Here the 64 columns of the B tile are FOUR TAPS x 16 channels: column
+// block s of accumulator j belongs to tap 4 j + s, i.e. each 16-lane column block of a transposed fragment read
+// simply starts at a different pixel of the G patch.  25 taps -> 7 accumulators (9 -> 3), all kernel rows in one
+// launch, a quarter of the MFMAs, and the G patch staged per tile is 16 channels instead of 64.
+template <int KS, int FMT>
+__global__ __launch_bounds__(512, 2) void wgrad_thin_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split, int ntiles,
+                                                           int with_bias) {
+  constexpr int NS = 2, TR = 4, TW = 16, PX = TR * TW, CH = 64, LD = CH + MT_WGPC_PAD, CG = 16, LDG = CG + 8;
+  constexpr int GH = TR - 1 + KS, GW = TW - 1 + KS, GP = GH * GW, PADK = KS / 2;
+  constexpr int ND4 = PX * (CH / 4), RD = ND4 / 256;
+  constexpr int NG4 = GP * (CG / 4), RG = (NG4 + 255) / 256;
+  constexpr int T = KS * KS, NG = (T + 3) / 4;
+  constexpr int D_E = NS * PX * LD, G_E = NS * GP * LDG, BUF_E = D_E + G_E;
+  __shared__ __attribute__((aligned(16))) __bf16 sm[2 * BUF_E];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool producer = wave >= 4;
+  const int at = blockIdx.x, a0 = at * CH;
+  const int split = blockIdx.y;
+  const int t_beg = split * tiles_per_split, t_end = min(ntiles, t_beg + tiles_per_split);
+  const float scD = FMT ? pow2_scale(*p.damax) : 1.f, scG = FMT ? pow2_scale(*p.gamax) : 1.f;
+  const float inv = 1.f / (scD * scG), inv_d = 1.f / scD;
+
+  if (producer) {
+    const int ptid = tid - 256;
+    f32x4 rd[2][RD], rg[2][RG];
+    const int rxD = ptid >> 4, c4 = (ptid & 15) * 4;
+    const bool chD = a0 + c4 < p.Cd;
+    const unsigned dsh = (unsigned)p.dsh, dsw = (unsigned)p.dsw, gsh = (unsigned)p.gsh, gsw = (unsigned)p.gsw;
+    const unsigned offD0 = rxD * dsw + a0 + c4;
+    // G: float4 idx = ptid + 256 i -> patch pixel idx >> 2, channels 4 (idx & 3)
+    const int cg4 = (ptid & 3) * 4;
+    int gyx[RG];
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+      const int gpx = (ptid >> 2) + 64 * i, gy = gpx / GW, gx = gpx - gy * GW;
+      gyx[i] = gy << 8 | gx;
+    }
+    auto load_tile = [&](int t, auto set_c) {
+      constexpr int S = decltype(set_c)::value;
+      const int tx = t % tiles_x, r = t / tiles_x, ty = r % tiles_y, n = r / tiles_y;
+      const int ty0 = ty * TR, tx0 = tx * TW, gy0 = ty0 - PADK, gx0 = tx0 - PADK;
+      const float* dp = p.d + (long)(n / p.dni) * p.dsg + (long)(n % p.dni) * p.dsn + (long)ty0 * p.dsh + (long)tx0 * p.dsw;
+      const float* gimg = p.g + (long)(n / p.gni) * p.gsg + (long)(n % p.gni) * p.gsn;
+#pragma unroll
+      for (int i = 0; i < RD; ++i) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ty0 + i < p.Hd && tx0 + rxD < p.Wd && chD) v = *reinterpret_cast<const f32x4*>(dp + i * dsh + offD0);
+        rd[S][i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < RG; ++i) {
+        const int ly = gy0 + (gyx[i] >> 8), lx = gx0 + (gyx[i] & 255);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ptid + 256 * i < NG4 && (unsigned)ly < (unsigned)p.Hg && (unsigned)lx < (unsigned)p.Wg)
+          v = *reinterpret_cast<const f32x4*>(gimg + (__umul24(ly, gsh) + __umul24(lx, gsw) + cg4));
+        rg[S][i] = v;
+      }
+    };
+    auto store_tile = [&](auto set_c) {
+      constexpr int S = decltype(set_c)::value;
+      __bf16* sD = sm + S * BUF_E;
+      __bf16* sG = sD + D_E;
+#pragma unroll
+      for (int i = 0; i < RD; ++i) {
+        const int idx = ptid + 256 * i, px = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
+        bf16x4 parts[NS];
+        split4f<NS, FMT, 1>(rd[S][i], scD, parts);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sD[s * PX * LD + px * LD + c]) = parts[s];
+      }
+#pragma unroll
+      for (int i = 0; i < RG; ++i) {
+        const int idx = ptid + 256 * i;
+        if (idx < NG4) {
+          bf16x4 parts[NS];
+          split4f<NS, FMT, 1>(rg[S][i], scG, parts);
+#pragma unroll
+          for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sG[s * GP * LDG + (idx >> 2) * LDG + cg4]) = parts[s];
+        }
+      }
+    };
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    const int nt = t_end - t_beg;
+    if (nt > 0) load_tile(t_beg, S0);
+    if (nt > 1) load_tile(t_beg + 1, S1);
+    if (nt > 0) store_tile(S0);
+    if (nt > 2) load_tile(t_beg + 2, S0);
+    __syncthreads();
+    for (int i = 0; i < nt; i += 2) {
+      if (i + 1 < nt) store_tile(S1);
+      if (i + 3 < nt) load_tile(t_beg + i + 3, S1);
+      __syncthreads();
+      if (i + 1 >= nt) break;
+      if (i + 2 < nt) store_tile(S0);
+      if (i + 4 < nt) load_tile(t_beg + i + 4, S0);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---- waves 0-3: MFMAs only ------------------------------------------------------------------
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const bool do_bias = with_bias != 0;
+  f32x16 acc_bias;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_bias[r] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = FMT ? __builtin_bit_cast(__bf16, (_Float16)1.0f) : (__bf16)1.0f;
+  const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, g1 = (lane >> 4) & 1, lh = lane >> 5;
+  const int a_off = (8 * lh + q) * LD + wm * 32 + 16 * g1 + 4 * pp;
+  // column block (wn, g1) of accumulator j = tap 4 j + 2 wn + g1: its fragment rows start at that tap's pixel
+  int b_off[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    int tap = 4 * j + 2 * wn + g1;
+    if (tap >= T) tap = T - 1;                 // (an unused column block: any valid address, its sums are dropped)
+    const int kh = tap / KS, kw = tap - kh * KS;
+    b_off[j] = (kh * GW + kw + 8 * lh + q) * LDG + 4 * pp;
+  }
+
+  __syncthreads();
+  for (int t = t_beg; t < t_end; ++t) {
+    const __bf16* sD = sm + ((t - t_beg) & 1) * BUF_E;
+    const __bf16* sG = sD + D_E;
+#pragma unroll
+    for (int ks = 0; ks < TR; ++ks) {
+      bf16x8 fa[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) fa[s] = tr_frag(sD + s * PX * LD, a_off + ks * 16 * LD, LD);
+      if (do_bias) {
+#pragma unroll
+        for (int s = NS - 1; s >= 0; --s) {
+          if constexpr (FMT == 0) acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], ones, acc_bias, 0, 0, 0);
+          else acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[s]), __builtin_bit_cast(half8, ones), acc_bias, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NG; ++j) {
+        bf16x8 fb[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fb[s] = tr_frag(sG + s * GP * LDG, b_off[j] + ks * GW * LDG, LDG);
+        mfma_splitf<NS, FMT>(fa, fb, acc[j]);
+      }
+    }
+    __syncthreads();
+  }
+
+  const int li = lane & 31;
+  const int TS = T + (with_bias ? 1 : 0);
+  float* slab = p.slabs + (long)split * p.Cd * TS * p.Cg;
+  if (do_bias && wn == 0 && li == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ai < p.Cd) slab[((long)ai * TS + T) * p.Cg] = acc_bias[r] * inv_d;
+    }
+  }
+  const int tap_s = 2 * wn + (li >> 4), bi = li & 15;
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const int tap = 4 * j + tap_s;
+    if (tap >= T) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ai < p.Cd) slab[((long)ai * TS + tap) * p.Cg + bi] = acc[j][r] * inv;
+    }
+  }
+}
+
 }  // namespace
 
 namespace {
@@ -492,6 +674,19 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
 #define MT_WGPC(KS, KHB, FMT, KH_BASE) \
   hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{})
+  // 16 gathered channels (and no up-sampled gather): four taps share a B tile (MT355_WGRAD_THIN=0: the kernel below)
+  static const bool thin_on = [] { const char* e = getenv("MT355_WGRAD_THIN"); return !(e && e[0] == '0'); }();
+  if (pc && thin_on && d->g.C == 16 && d->ups == 0 && !d->skip_tiles) {
+    const dim3 grid(k.atiles, d->splits);
+    if (d->KH == 3) {
+      if (prec == MT_PREC_F16X3) hipLaunchKernelGGL((wgrad_thin_kernel<3, 1>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
+      else hipLaunchKernelGGL((wgrad_thin_kernel<3, 0>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
+    } else {
+      if (prec == MT_PREC_F16X3) hipLaunchKernelGGL((wgrad_thin_kernel<5, 1>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
+      else hipLaunchKernelGGL((wgrad_thin_kernel<5, 0>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
+    }
+    return 1;
+  }
   if (pc) {
     const bool f16 = prec == MT_PREC_F16X3;
     if (d->KH == 3) { if (f16) MT_WGPC(3, 3, 1, 0); else MT_WGPC(3, 3, 0, 0); }

@@ -788,7 +788,9 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     d.d_amax, keep1 = _amax_ptr(prec, da, dv)
     d.g_amax, keep2 = _amax_ptr(prec, ga, gv)
     if halo:
-        kname = (f'wgrad_pc_kernel<{spec.k},{3 if spec.k == 3 else "2+2+1"},{"f16" if prec == "f16x3" else "bf16"}>' if pc else
+        thin = pc and bp == 16 and d.ups == 0 and sub_blocks is None and os.environ.get('MT355_WGRAD_THIN', '1') != '0'
+        kname = f'wgrad_thin_kernel<{spec.k},{"f16" if prec == "f16x3" else "bf16"}>' if thin else \
+                (f'wgrad_pc_kernel<{spec.k},{3 if spec.k == 3 else "2+2+1"},{"f16" if prec == "f16x3" else "bf16"}>' if pc else
                  f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else (1 if rows5 else "3+2")},{_HTAG[prec]}>')
     else:
         kname = ('wgrad_kernel' if prec == 'f32' else 'wgrad_split_kernel') + f'<{wcfg}{_KTAG[prec]}>'

@@ -18,11 +18,11 @@ step(); step()
 log = []
 orig = L.call
 def call(name, *a):
-    if name in ('mt_conv_run', 'mt_wgrad_run', 'mt_conv_tiny_in_run', 'mt_wgrad_tiny_run'):
+    if name in ('mt_conv_run', 'mt_wgrad_run', 'mt_conv_tiny_in_run', 'mt_conv_tiny_out_run', 'mt_wgrad_tiny_run'):
         d = a[0]._obj
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); r = orig(name, *a); e1.record()
-        if name in ('mt_conv_run', 'mt_conv_tiny_in_run'):
+        if name in ('mt_conv_run', 'mt_conv_tiny_in_run', 'mt_conv_tiny_out_run'):
             log.append((name, (d.x.N, d.x.H, d.x.W, d.x.C, d.y.H, d.y.W, d.y.C, d.KH, d.stride, d.transposed, d.ups), e0, e1))
         else:
             log.append((name, (d.d.N, d.d.H, d.d.W, d.d.C, d.g.H, d.g.W, d.g.C, d.KH, d.stride, 0, d.ups), e0, e1))

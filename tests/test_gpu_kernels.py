@@ -72,6 +72,10 @@ CONV_CASES = [
     (1, 21, 13, 3, 64, 3, 1, 'c', 1),
     (2, 13, 9, 128, 1, 3, 1, 'c', 0),
     (1, 17, 33, 64, 3, 3, 1, 'c', 1),
+    # 16 gathered channels: the weight gradient with four taps per B tile (5x5: 7 accumulators, 3x3: 3), ragged tiles
+    (2, 21, 19, 10, 128, 5, 1, 'c', 1),
+    (1, 18, 35, 9, 64, 3, 1, 'c', 0),
+    (2, 9, 16, 16, 192, 3, 1, 'c', 2),
 ]
 
 
