@@ -308,10 +308,20 @@ def spawn_ranks(args):
 
 
 # ------------------------------------------------------------------ one rank ---
+def claim_stdout():
+    """The contract is ONE JSON line on stdout, but RCCL and gloo print banners to file descriptor 1 when a
+    communicator comes up.  From here on fd 1 is stderr for everybody; the returned file is the real stdout."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+    return real
+
+
 def run_rank(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    real_stdout = claim_stdout()
     if args.gpus != world:
         print(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)', file=sys.stderr)
         sys.exit(2)
@@ -459,7 +469,7 @@ def run_rank(args):
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(dfpn, chn, batch, min(args.cpu_clips, args.batch), args.cpu_steps)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -12,7 +12,7 @@ import csv, glob, collections
 for f in sorted(glob.glob('$out/p*/**/*counter_collection.csv', recursive=True)):
     acc = collections.defaultdict(list); dur = []
     for r in csv.DictReader(open(f)):
-        if 'wgrad_' in r['Kernel_Name']:
+        if 'wgrad_pc_kernel' in r['Kernel_Name']:
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
             dur.append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) / 1e3)
     print(f.split('/')[2], 'avg us', sum(dur) / max(1, len(dur)), 'n', len(dur))
