@@ -143,6 +143,13 @@ int mt_conv_run(const mt_conv* d, void* stream);
  * transposed must be off. */
 int mt_conv_tiny_in_run(const mt_conv* d, const float* w, int32_t cin, int64_t so, int64_t si, int64_t st,
                         int32_t flip, void* stream);
+/* The mirror case: 128 gathered channels, ONE or TWO output channels, stride-1 3x3 / 5x5 "same" (the 128 -> 2 exit
+ * of FlowEstimator model_dfpn.py:710, the 128 -> 1 exit of SeparableConv4d model_dfpn.py:604, and the backward-data
+ * of FlowEstimator's 10 -> 128 entry model_dfpn.py:688, of which only the two flow channels are read).  zero_fill = 1
+ * writes whole pixels of y (result in channels 0 .. cout-1, zeros in the padding); zero_fill = 0 writes only channels
+ * co_off .. co_off+cout-1.  Supported of mt_conv: x / y views, bias, act, alpha, y_amax. */
+int mt_conv_tiny_out_run(const mt_conv* d, const float* w, int32_t cout, int64_t so, int64_t si, int64_t st,
+                         int32_t flip, int32_t co_off, int32_t zero_fill, void* stream);
 /* slow one-thread-per-output restatement of mt_conv_run (self-check only) */
 int mt_conv_run_naive(const mt_conv* d, void* stream);
 

@@ -79,6 +79,7 @@ SIGNATURES = {
     'mt_conv_run': [_P(Conv), _vp],
     'mt_conv_run_naive': [_P(Conv), _vp],
     'mt_conv_tiny_in_run': [_P(Conv), _vp, i32, i64, i64, i64, i32, _vp],
+    'mt_conv_tiny_out_run': [_P(Conv), _vp, i32, i64, i64, i64, i32, i32, i32, _vp],
     'mt_wgrad_run': [_P(Wgrad), _vp],
     'mt_wgrad_run_batch': [_vp, i32, _vp],
     'mt_wgrad_tiny_run': [_P(Wgrad), i32, _vp],

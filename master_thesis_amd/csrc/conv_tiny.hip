@@ -236,6 +236,130 @@ __global__ __launch_bounds__(256) void wgrad_tiny_kernel(WgK p, int with_bias, i
   }
 }
 
+// ---- forward / backward-data: stride-1 3x3 / 5x5 "same", 128 input channels, ONE or TWO output channels ------
+// (the 128 -> 2 exit of FlowEstimator, the 128 -> 1 exit of SeparableConv4d, and the backward-data of
+// FlowEstimator's 10 -> 128 entry, of which only the two flow channels are ever read: ops.PackFlowEstimatorFn.)
+// A thread group (32 lanes = the 128 channels, a float4 each) walks DOWN a strip of 8 output columns: every input
+// row of the strip is loaded once (8 + KS - 1 pixels, whole 512-byte pixel rows per group; the next row's loads
+// are in flight while this one is multiplied) and scattered into the KS output rows it belongs to -- a ring of
+// KS x NO x 8 partial sums per lane.  When an output row has seen its KS input rows, the 32 lanes are added by a
+// reduce-scatter of shuffles and the row is written.  No input pixel is read twice inside a strip.
+template <int KS, int NO>
+__global__ __launch_bounds__(256) void conv_tiny_out_kernel(ConvK p, const float* __restrict__ w, long so, long si, long st,
+                                                          int flip, int co_off, int zero_fill, int strips_x, int segs_y,
+                                                          int seg_rows, int nwork) {
+  constexpr int LG = 32, NGRP = 256 / LG, SW = 8, XW = SW + KS - 1, PAD = KS / 2, T = KS * KS, NV = NO * SW;
+  __shared__ __attribute__((aligned(16))) float sW[T * NO][4 * LG];
+  const int tid = threadIdx.x, g = tid / LG, l = tid % LG;
+  for (int idx = tid; idx < T * NO * 4 * LG; idx += 256) {
+    const int k = idx / (4 * LG), ci = idx - k * (4 * LG);
+    const int tap = k / NO, co = k - tap * NO;
+    sW[k][ci] = w[co * so + ci * si + (flip ? T - 1 - tap : tap) * st];
+  }
+  __syncthreads();
+  float vmax = 0.f;
+  // one work item = (image, vertical segment, strip); a group takes items g + NGRP * (blockIdx.x + gridDim.x * k)
+  for (int item = blockIdx.x * NGRP + g; item < nwork; item += gridDim.x * NGRP) {
+    const int sx = item % strips_x, r_ = item / strips_x, sy = r_ % segs_y, n = r_ / segs_y;
+    const int x0 = sx * SW, y0 = sy * seg_rows, y1 = min(p.Ho, y0 + seg_rows);       // output rows y0 .. y1-1
+    const float* xin = p.x + (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn + 4 * l;
+    float* yimg = p.y + (long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn;
+    float acc[KS][NV];                      // acc[dy]: the output row this input row feeds through kernel row dy
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int j = 0; j < NV; ++j) acc[s][j] = 0.f;
+    auto load_row = [&](float4 (&xr)[XW], int iy) {
+#pragma unroll
+      for (int c = 0; c < XW; ++c) {
+        const int ix = x0 + c - PAD;
+        float4 t = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          t = *reinterpret_cast<const float4*>(xin + (long)iy * p.xsh + (long)ix * p.xsw);
+        xr[c] = t;
+      }
+    };
+    const int iy_end = y1 + PAD;            // input rows y0 - PAD .. y1 - 1 + PAD
+    // one input row: the next row's loads are issued first, then this row is scattered into its KS output rows
+    auto row = [&](float4 (&cur)[XW], float4 (&nxt)[XW], int iy) {
+      if (iy + 1 < iy_end) load_row(nxt, iy + 1);
+#pragma unroll
+      for (int dy = 0; dy < KS; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < KS; ++dx)
+#pragma unroll
+          for (int co = 0; co < NO; ++co) {
+            const float4 wv = *reinterpret_cast<const float4*>(&sW[(dy * KS + dx) * NO + co][4 * l]);
+#pragma unroll
+            for (int i = 0; i < SW; ++i) {
+              const float4 x = cur[i + dx];
+              acc[dy][co * SW + i] = fmaf(x.x, wv.x, fmaf(x.y, wv.y, fmaf(x.z, wv.z, fmaf(x.w, wv.w, acc[dy][co * SW + i]))));
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);   // (keeps the weight reads of one kernel row at a time in registers)
+      }
+      // output row oy = iy - PAD has now seen all its kernel rows (it sits in acc[KS - 1])
+      const int oy = iy - PAD;
+      if (oy >= y0 && oy < y1) {
+        float v[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = acc[KS - 1][j];
+        int cnt = NV;
+#pragma unroll
+        for (int m = LG / 2; m >= 1; m >>= 1) {
+          if (cnt > 1) {
+            const int half = cnt / 2;
+            const bool up = (l & m) != 0;
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+              const float send = up ? v[j] : v[j + half], keep = up ? v[j + half] : v[j];
+              v[j] = keep + __shfl_xor(send, m, 64);
+            }
+            cnt = half;
+          } else {
+            v[0] += __shfl_xor(v[0], m, 64);
+          }
+        }
+        // NV = 16: value index = l >> 1 (both lanes of a pair hold it); NV = 8: l >> 2
+        const int idx = NV == 16 ? (l >> 1) : (l >> 2);
+        const int co = idx / SW, i = idx - co * SW;
+        float val = v[0];
+        if (p.bias) val += p.bias[co];
+        val = mt_act_fn(val, p.act) * p.alpha;
+        float val1 = 0.f;
+        if (NO == 2) val1 = __shfl_xor(val, 16, 64);        // the lane of (0, i) fetches output (1, i)
+        const bool writer = NO == 2 ? (l < 16 && (l & 1) == 0) : ((l & 3) == 0);
+        const int ox = x0 + i;
+        if (writer && ox < p.Wo) {
+          float* yp = yimg + (long)oy * p.ysh + (long)ox * p.ysw;
+          if (zero_fill) {
+            *reinterpret_cast<float4*>(yp) = float4{val, val1, 0.f, 0.f};
+            for (int c = 4; c < p.Co; c += 4) *reinterpret_cast<float4*>(yp + c) = float4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            yp[co_off] = val;
+            if (NO == 2) yp[co_off + 1] = val1;
+          }
+          vmax = fmaxf(vmax, fmaxf(fabsf(val), fabsf(val1)));
+        }
+      }
+      // the next input row sees every output row one kernel row later
+#pragma unroll
+      for (int s = KS - 1; s > 0; --s)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc[s][j] = acc[s - 1][j];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) acc[0][j] = 0.f;
+    };
+    float4 xa[XW], xb[XW];
+    load_row(xa, y0 - PAD);
+    for (int iy = y0 - PAD; iy < iy_end; iy += 2) {
+      row(xa, xb, iy);
+      if (iy + 1 < iy_end) row(xb, xa, iy + 1);
+    }
+  }
+  if (p.yamax) raise_amax(p.yamax, vmax);
+}
+
 bool tiny_enabled() {
   static const bool on = [] { const char* e = getenv("MT355_TINY"); return !(e && e[0] == '0'); }();
   return on;
@@ -306,4 +430,42 @@ extern "C" int mt_wgrad_tiny_run(const mt_wgrad* d, int32_t tiny, void* stream) 
 #undef MT_WT_NT
 #undef MT_WT
   return mt_check_launch("mt_wgrad_tiny_run");
+}
+
+// Stride-1 3x3 / 5x5 "same" convolution of a 128-channel tensor to `cout` = 1 or 2 output channels, fp32 on the
+// VALU.  w[co * so + ci * si + tap * st]; flip as in mt_conv_tiny_in_run.  zero_fill = 1: every pixel of y is
+// written whole (channels co_off = 0 .. cout-1 hold the result, the padding channels zeros); zero_fill = 0: only
+// channels co_off .. co_off + cout - 1 of y are written (a window of a wider gradient tensor whose other channels
+// nobody reads).  Supported of mt_conv: x / y views, bias, act, alpha, y_amax; no residual / gating / accumulate.
+extern "C" int mt_conv_tiny_out_run(const mt_conv* d, const float* w, int32_t cout, int64_t so, int64_t si, int64_t st,
+                                    int32_t flip, int32_t co_off, int32_t zero_fill, void* stream) {
+  MT_REQUIRE(d && w && (cout == 1 || cout == 2), "mt_conv_tiny_out_run: 1 or 2 output channels (got %d)", cout);
+  mt_conv e = *d;
+  e.wt = d->x.p;
+  ConvK k;
+  const int rc = fill_convk(&e, &k);
+  if (rc) return rc;
+  MT_REQUIRE(tiny_enabled(), "mt_conv_tiny_out_run: disabled (MT355_TINY=0)");
+  MT_REQUIRE(d->stride == 1 && d->KH == d->KW && (d->KH == 3 || d->KH == 5) && d->pad == d->KH / 2 && d->ups == 0 && !d->transposed,
+             "mt_conv_tiny_out_run: stride-1 3x3 / 5x5 'same' layers only");
+  MT_REQUIRE(d->x.C == 128, "mt_conv_tiny_out_run: 128 input channels (got %d)", d->x.C);
+  MT_REQUIRE(co_off >= 0 && co_off + cout <= d->y.C && (!zero_fill || co_off == 0), "mt_conv_tiny_out_run: channel window outside y");
+  MT_REQUIRE(!d->res.p && !d->accumulate && !d->dsrc.p, "mt_conv_tiny_out_run: no residual / accumulate / gating");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // vertical segments: tall enough that the KS - 1 halo rows are a small share, short enough for >= 4096 work items
+  const int strips_x = (k.Wo + 7) / 8;
+  // (measured at 256^2: 8 .. 128 rows per segment all within 10 %; at 64^2 only the short segments fill the chip)
+  int seg_rows = 64;
+  while (seg_rows > 16 && (long)k.N * strips_x * ((k.Ho + seg_rows - 1) / seg_rows) < 4096) seg_rows >>= 1;
+  if (seg_rows > k.Ho) seg_rows = k.Ho;
+  const int segs_y = (k.Ho + seg_rows - 1) / seg_rows;
+  const long nwork = (long)k.N * strips_x * segs_y;
+  MT_REQUIRE(nwork < (1L << 31), "mt_conv_tiny_out_run: too many strips");
+  const long nblk = (nwork + 7) / 8;
+  const dim3 grid((unsigned)(nblk < 1024 ? nblk : 1024));
+#define MT_TO(KS, NO) hipLaunchKernelGGL((conv_tiny_out_kernel<KS, NO>), grid, dim3(256), 0, s, k, w, (long)so, (long)si, (long)st, flip, co_off, zero_fill, strips_x, segs_y, seg_rows, (int)nwork)
+  if (d->KH == 3) { if (cout == 1) MT_TO(3, 1); else MT_TO(3, 2); }
+  else { if (cout == 1) MT_TO(5, 1); else MT_TO(5, 2); }
+#undef MT_TO
+  return mt_check_launch("mt_conv_tiny_out_run");
 }

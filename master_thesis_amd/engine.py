@@ -92,7 +92,14 @@ WGRAD_PC5 = os.environ.get('MT355_WGRAD_PC5', '1') != '0'  # 5x5 on the producer
 WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '512'))
 HALO_RB32 = os.environ.get('MT355_HALO_RB32', '0') == '1'  # mirrors halo_rb32_wanted() in conv_halo.hip (off by default)
 HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_enabled() in conv_halo_wino.hip
+TINY_OUT = os.environ.get('MT355_TINY_OUT', '1') != '0'   # ... and for 128 -> 1 / 2 channel layers (A/B switch)
 TINY = os.environ.get('MT355_TINY', '1') != '0'           # fp32 VALU kernels for layers with <= 4 channels on one side (conv_tiny.hip)
+
+
+def tiny_out_eligible(kind_c, stride, k, pad, ups, cin_real, x_cp, cout_n):
+    """mt_conv_tiny_out_run takes the layer: stride-1 3x3 / 5x5 'same', 128 gathered channels, 1 or 2 outputs."""
+    return (TINY and TINY_OUT and USE_HALO and kind_c and stride == 1 and k in (3, 5) and pad == k // 2 and ups == 0
+            and cin_real == 128 and x_cp == 128 and cout_n in (1, 2))
 
 
 def tiny_in_eligible(kind_c, stride, k, pad, ups, cin_real, cout_real, x_cp):
@@ -495,6 +502,9 @@ class LayerSpec:
         self.kind, self.cin, self.cout, self.k = kind, cin, cout, k
         self.stride, self.pad, self.act, self.ups = stride, k // 2, act, ups
         self.swap_groups = swap_groups
+        # (c0, n): of the gradient wrt this layer's INPUT only channels c0 .. c0+n-1 are ever read (the first layer
+        # of FlowEstimator: ops.PackFlowEstimatorFn differentiates the two flow channels only); None = all of it
+        self.dx_window = None
 
     def out_hw(self, h, w):
         h, w = h << self.ups, w << self.ups
@@ -553,6 +563,19 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
         with _Prof('conv_tiny_in_kernel', 2.0 * n * ho * wo * spec.cin * spec.cout * 9):
             L.call('mt_conv_tiny_in_run', C.byref(d), L.ptr(w), spec.cin, spec.cin * 9, 9, 1, 0, L.stream_ptr())
         return out
+    if (res is None and w.is_contiguous()
+            and tiny_out_eligible(spec.kind == 'c', spec.stride, spec.k, spec.pad, spec.ups, spec.cin, xv.C, spec.cout)):
+        pb = _pad_bias(b, spec.cout)
+        d.bias = pb.data_ptr() if pb is not None else None
+        d.KH = d.KW = spec.k
+        d.stride, d.pad, d.ups, d.transposed = 1, spec.pad, 0, 0
+        d.act, d.alpha, d.beta = spec.act, alpha, 0.0
+        d.res, d.dsrc = null_view(), null_view()
+        d.y_amax, keep_y = _out_amax(prec, y_amax, out)
+        kk = spec.k * spec.k
+        with _Prof('conv_tiny_out_kernel', 2.0 * n * ho * wo * spec.cin * spec.cout * kk):
+            L.call('mt_conv_tiny_out_run', C.byref(d), L.ptr(w), spec.cout, spec.cin * kk, kk, 1, 0, 0, 1, L.stream_ptr())
+        return out
     transposed = 0 if spec.kind == 'c' else 1
     planes = planes_eligible(spec.stride, spec.k, xv.C, out.shape[3], prec, spec.ups)
     packed, wa = _pack(w, 0 if spec.kind == 'c' else 1, 'f', prec, halo=halo, planes=transposed if planes else None)
@@ -584,7 +607,7 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
 
 
 def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, accumulate=False, alpha=1.0,
-                       dz_amax=None, y_amax=None, packed=None, res=None, beta=0.0):
+                       dz_amax=None, y_amax=None, packed=None, res=None, beta=0.0, dx_window=None):
     """dIn = bwd-data(dZ) written through the view ``yv`` (the layer's input
     geometry), optionally gated by act'(dsrc) (the previous layer's saved
     output)."""
@@ -596,6 +619,23 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     # conv so that it takes the halo-tile kernel
     as_fwd = halo_eligible(spec.kind == 'c', spec.stride, spec.k, dz.shape[3])
     prec = eff_precision(as_fwd)
+    if (dx_window is not None and packed is None and res is None and not accumulate and dsrc is None and w is not None
+            and w.is_contiguous()
+            and tiny_out_eligible(spec.kind == 'c', spec.stride, spec.k, spec.pad, 0, spec.cout, dzv.C, dx_window[1])):
+        # only channels c0 .. c0+n-1 of the input gradient are wanted: a 128 -> n forward conv of dZ with the
+        # tap-reversed kernel, written into that channel window (the rest of yv stays unwritten)
+        c0, nch = dx_window
+        kk = spec.k * spec.k
+        d.bias = None
+        d.KH = d.KW = spec.k
+        d.stride, d.pad, d.ups, d.transposed = 1, spec.pad, 0, 0
+        d.act, d.alpha, d.beta = L.ACT_NONE, alpha, 0.0
+        d.res, d.dsrc = null_view(), null_view()
+        d.y_amax = None
+        with _Prof('conv_tiny_out_kernel', 2.0 * dzv.N * dzv.H * dzv.W * nch * spec.cout * kk):
+            L.call('mt_conv_tiny_out_run', C.byref(d), C.c_void_p(w.data_ptr() + 4 * c0 * kk), nch, kk, spec.cin * kk, 1, 1,
+                   c0, 0, L.stream_ptr())
+        return
     if (packed is None and res is None and not accumulate and dact_c0 == 0 and w is not None and w.is_contiguous()
             and yv.C == spec.cin
             and tiny_in_eligible(spec.kind == 'c', spec.stride, spec.k, spec.pad, 0, spec.cout, spec.cin, dzv.C)):
@@ -930,7 +970,8 @@ class ConvStackFn(torch.autograd.Function):
             prev_act = specs[i - 1].act if i > 0 else L.ACT_NONE
             if sp.swap_groups:
                 assert prev_act == L.ACT_NONE
-            conv_backward_data(sp, dz, w, yv, dsrc=xin if prev_act != L.ACT_NONE else None, dact=prev_act)
+            conv_backward_data(sp, dz, w, yv, dsrc=xin if prev_act != L.ACT_NONE else None, dact=prev_act,
+                               dx_window=sp.dx_window if i == 0 else None)
             dz = dx
             acts[i + 1] = None   # release the saved activation
         return (dz, None, None) + tuple(grads)

@@ -346,5 +346,6 @@ class FlowEstimator(nn.Module):
         b, c, ref_n, h, w = x_refs.size()
         nn_input = ops.PackFlowEstimatorFn.apply(x_target, m_target, x_refs, m_refs, flow_pre, scale, shift)
         specs, params = _specs_from(self.nn)
+        specs[0].dx_window = (8, 2)       # PackFlowEstimatorFn reads the gradient of the two flow channels only
         out = E.conv_stack(nn_input, specs, params)            # (b*r,h,w,4)
         return out[..., :2].reshape(b, ref_n, h, w, 2)

@@ -76,6 +76,10 @@ CONV_CASES = [
     (2, 21, 19, 10, 128, 5, 1, 'c', 1),
     (1, 18, 35, 9, 64, 3, 1, 'c', 0),
     (2, 9, 16, 16, 192, 3, 1, 'c', 2),
+    # 128 -> 1 / 2 outputs on the fp32 VALU strip kernel: ragged strips and segments, 5x5, with an activation
+    (2, 37, 21, 128, 2, 5, 1, 'c', 1),
+    (1, 70, 13, 128, 1, 5, 1, 'c', 0),
+    (3, 19, 30, 128, 2, 3, 1, 'c', 2),
 ]
 
 
@@ -200,6 +204,33 @@ def test_tiny_exit_layer_gates_by_the_saved_activation(mt):
     assert_close(yd, y, what='forward')
     yd.backward(gy.to(dev()))
     assert_close(xg.grad, xr.grad, what='bwd-data')
+    for a, b in zip(pg, pr):
+        assert_close(a.grad, b.grad, what='parameter gradient')
+
+
+def test_input_gradient_window_of_the_flow_estimator_entry(mt):
+    """conv(10 -> 128, 5x5, ReLU) -> conv(128 -> 128, 3x3) with dx_window = (8, 2): only the two flow channels of
+    the input gradient are produced (fp32 VALU kernel, tap-reversed weights of input channels 8 and 9), and they
+    match torch's full input gradient there (model_dfpn.py:688, ops.PackFlowEstimatorFn)."""
+    from master_thesis_amd import engine as E
+    from master_thesis_amd import _lib as L
+    specs = [E.LayerSpec('c', 10, 128, 5, 1, L.ACT_RELU), E.LayerSpec('c', 128, 128, 3, 1, L.ACT_NONE)]
+    specs[0].dx_window = (8, 2)
+    shapes = [(128, 10, 5, 5), (128,), (128, 128, 3, 3), (128,)]
+    ps = [S.uniform(f'dxwin.p{i}', s, -0.1, 0.1) for i, s in enumerate(shapes)]
+    x = S.uniform('dxwin.x', (2, 10, 19, 23), -1, 1)
+    pr = [p.clone().requires_grad_(True) for p in ps]
+    xr = x.clone().requires_grad_(True)
+    y = F.conv2d(F.relu(F.conv2d(xr, pr[0], pr[1], padding=2)), pr[2], pr[3], padding=1)
+    gy = S.uniform('dxwin.gy', tuple(y.shape), -1, 1)
+    y.backward(gy)
+    x4 = E.to_nhwc4(x.to(dev())).requires_grad_(True)
+    pg = [p.to(dev()).requires_grad_(True) for p in ps]
+    y4 = E.conv_stack(x4, specs, pg)
+    assert_close(E.from_nhwc4(y4.detach(), 128), y, what='forward')
+    y4.backward(E.to_nhwc4(gy.to(dev())))
+    got = x4.grad[..., 8:10].permute(0, 3, 1, 2)
+    assert_close(got, xr.grad[:, 8:10], what='flow-channel input gradient')
     for a, b in zip(pg, pr):
         assert_close(a.grad, b.grad, what='parameter gradient')
 
