@@ -98,9 +98,11 @@ def timed_steps(step_fn, steps, warmup, world):
 
 
 def kernel_profile(step_fn):
-    """One extra step with HIP events around every conv-engine launch (on the stream they run
-    on): per-kernel launches, total ms and algorithmic FLOP."""
+    """Two extra eager steps, the second with HIP events around every conv-engine launch (on the
+    stream they run on): per-kernel launches, total ms and algorithmic FLOP."""
     from master_thesis_amd import engine as E
+    step_fn()                     # untimed: the eager path's allocations and clocks settle after the graph replays
+    torch.cuda.synchronize()
     E.PROFILE = []
     step_fn()
     torch.cuda.synchronize()
@@ -394,6 +396,7 @@ def run_rank(args):
             res['kernels'] = kernels_table(agg)
             res['_agg'] = agg
         else:
+            eager()
             eager()
         return res, opt
 
