@@ -235,6 +235,34 @@ def test_input_gradient_window_of_the_flow_estimator_entry(mt):
         assert_close(a.grad, b.grad, what='parameter gradient')
 
 
+def test_batched_weight_gradients_match_single_launches(mt):
+    """engine.WgradBatch / mt_wgrad_run_batch: three 3x3 layers of one geometry recorded and launched as one grid
+    give the gradients of three separate mt_wgrad_run launches (the dense blocks of the RRDB trunk)."""
+    from master_thesis_amd import engine as E
+    spec = E.LayerSpec('c', 96, 64, 3, 1, 0)
+    probs = []
+    for i in range(3):
+        x = S.uniform(f'wbatch.x{i}', (2, 20, 28, 96), -1, 1).to(dev())
+        dz = S.uniform(f'wbatch.dz{i}', (2, 20, 28, 64), -1, 1).to(dev())
+        w = S.uniform(f'wbatch.w{i}', (64, 96, 3, 3), -0.1, 0.1).to(dev())
+        probs.append((x, dz, w))
+    with E.precision('f16x3'):
+        single = [E.conv_backward_weight(spec, dz, E.view_of(x), w) for x, dz, w in probs]
+        batch = E.WgradBatch()
+        deferred = [E.conv_backward_weight(spec, dz, E.view_of(x), w, defer=batch) for x, dz, w in probs]
+        assert len(batch.items) == 3, 'the layers were not deferred'
+        batch.flush()
+    for (dw0, db0), (dw1, db1) in zip(single, deferred):
+        assert_close(dw1, dw0, tol=1e-5, what='batched weight gradient')
+        assert_close(db1, db0, tol=1e-5, what='batched bias gradient')
+    # and against torch
+    x, dz, w = probs[1]
+    xr = x.permute(0, 3, 1, 2).contiguous().cpu()
+    wr = w.cpu().clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, padding=1).backward(dz.permute(0, 3, 1, 2).contiguous().cpu())
+    assert_close(deferred[1][0], wr.grad, what='batched weight gradient vs torch')
+
+
 def test_conv_stack_chain(mt, precision):
     """A 3-layer chain with fused ReLU gating in the backward."""
     from master_thesis_amd import engine as E
