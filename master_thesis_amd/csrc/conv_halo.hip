@@ -19,9 +19,11 @@
 
 namespace {
 
-template <int KS, int NS, int FMT, int WGM, int WGN, int TM, int TN>
+// CKP = 16 with two-term splits: layers with <= 16 input channels (FlowEstimator's 10 -> 128 entry, RRDBNet's
+// 9 -> 64): a 32-channel stage would be half zeros -- half the MFMAs, half the LDS image and weight tiles.
+template <int KS, int NS, int FMT, int WGM, int WGN, int TM, int TN, int CKP = (NS == 3 ? 16 : 32)>
 __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y, int tiles_x) {
-  constexpr int CK = NS == 3 ? 16 : 32;             // input channels per LDS stage
+  constexpr int CK = CKP;                           // input channels per LDS stage
   constexpr int LD = CK + 8;                        // bf16 per LDS row (+16 B pad)
   constexpr int TH = 8, TW = 16;
   static_assert(WGM * TM * 32 == TH * TW, "pixel tile is 8 x 16");
@@ -495,6 +497,14 @@ bool halo_rb_wanted(int cin_p, int cout_p) {
   return on && cin_p > 32 && cout_p > 32;
 }
 
+// Input channels per LDS stage of igemm_halo_kernel and of its weight tiles: 16 for the three-term split and for
+// layers whose (padded) input has at most 16 channels, else 32.  Kernel launch, pack routines and size queries
+// all go through this.
+#ifndef MT_HALO_THIN_CK
+#define MT_HALO_THIN_CK 1      // (0: 32-channel stages for every two-term layer -- A/B builds)
+#endif
+__host__ __device__ inline int halo_ck(int cin_p, int ns) { return (ns == 3 || (MT_HALO_THIN_CK && cin_p <= 16)) ? 16 : 32; }
+
 }  // namespace
 bool halo_wino_enabled();                                            // conv_halo_wino.hip
 bool halo_wino_mf16();
@@ -523,6 +533,17 @@ void launch_halo(const ConvK& k, hipStream_t s) {
         hipLaunchKernelGGL((igemm_halo_rb_kernel<KS, FMT, 1>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, tiles_y, tiles_x);
       else
         hipLaunchKernelGGL((igemm_halo_rb_kernel<KS, FMT, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+      return;
+    }
+  }
+  if constexpr (NS == 2) {
+    if (halo_ck(k.C, NS) == 16) {          // <= 16 input channels: 16-channel stages (the packs follow: halo_ck)
+      if (k.Co > 64)
+        hipLaunchKernelGGL((igemm_halo_kernel<KS, NS, FMT, 2, 2, 2, 2, 16>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, tiles_y, tiles_x);
+      else if (k.Co > 32)
+        hipLaunchKernelGGL((igemm_halo_kernel<KS, NS, FMT, 2, 2, 2, 1, 16>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+      else
+        hipLaunchKernelGGL((igemm_halo_kernel<KS, NS, FMT, 4, 1, 1, 1, 16>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
       return;
     }
   }
@@ -663,7 +684,7 @@ __global__ void weight_pack_jobs_kernel(const mt_pack_job* jobs) {
                     j.w_amax);
     return;
   }
-  const int CK = NS == 3 ? 16 : 32;
+  const int CK = halo_ck(j.BP_total, NS);
   const int BN = j.AP > 64 ? 128 : (j.AP > 32 ? 64 : 32);
   const int nchunk = (j.BP + CK - 1) / CK, ntile = (j.AP + BN - 1) / BN;
   const int nchunk_total = (j.BP_total + CK - 1) / CK, ch_off = j.b_off / CK;
@@ -688,7 +709,7 @@ __global__ void absmax_segments_kernel(const mt_amax_seg* segs) {
 }  // namespace
 
 extern "C" int64_t mt_weight_pack_halo_elems(int32_t AP, int32_t BP, int32_t T, int32_t precision) {
-  const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = NS == 3 ? 16 : 32, LD = CK + 8;
+  const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = halo_ck(BP, NS), LD = CK + 8;
   const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);
   if (NS == 2 && halo_wino_wanted(BP, AP, T)) T = 12;      // the (ky, xi) "taps" of the Winograd image (fragment order)
   return (int64_t)T * ((BP + CK - 1) / CK) * ((AP + BN - 1) / BN) * NS * BN * LD;
@@ -702,7 +723,7 @@ static int pack_halo_impl(const float* src, int32_t A, int32_t B, int32_t T, int
   MT_REQUIRE(precision == MT_PREC_BF16X3 || precision == MT_PREC_BF16X6 || precision == MT_PREC_F16X3,
              "mt_weight_pack_halo: precision");
   MT_REQUIRE((precision == MT_PREC_F16X3) == (w_amax != nullptr), "mt_weight_pack_halo: w_amax goes with F16X3");
-  const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = NS == 3 ? 16 : 32;
+  const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = halo_ck(BP_total, NS);
   MT_REQUIRE(b_off >= 0 && b_off % CK == 0 && b_off + BP <= BP_total && (b_off + BP == BP_total || BP % CK == 0),
              "mt_weight_pack_halo_part: a part must cover whole %d-channel K chunks", CK);
   const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);        // the n-tile igemm_halo uses for Co = AP
@@ -769,7 +790,7 @@ extern "C" int mt_weight_pack_jobs(const mt_pack_job* jobs_dev, const mt_pack_jo
                "mt_weight_pack_jobs: job %d: precision", i);
     MT_REQUIRE((j.precision == MT_PREC_F16X3) == (j.w_amax != nullptr), "mt_weight_pack_jobs: job %d: w_amax goes with F16X3", i);
     if (j.kind == MT_PACK_HALO) {
-      const int CK = j.precision == MT_PREC_BF16X6 ? 16 : 32;
+      const int CK = halo_ck(j.BP_total, j.precision == MT_PREC_BF16X6 ? 3 : 2);
       MT_REQUIRE(j.frag_order == mt_weight_pack_halo_frag_order(j.AP, j.BP_total, j.T, j.precision),
                  "mt_weight_pack_jobs: job %d: frag_order must be mt_weight_pack_halo_frag_order()", i);
       MT_REQUIRE((j.BP & 7) == 0 && j.b_off >= 0 && j.b_off % CK == 0 && j.b_off + j.BP <= j.BP_total &&
