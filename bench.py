@@ -292,11 +292,44 @@ def bench_cpu_config1(args):
 
 
 # --------------------------------------------------------- --gpus N launcher ---
+def visible_gpu_count():
+    """GPUs this process could open, counted WITHOUT any HIP / torch.cuda call (the launcher parent must not
+    initialise a GPU before it starts the ranks): KFD topology nodes that have SIMDs and whose DRM render node
+    this user may open, cut by the *_VISIBLE_DEVICES lists.  Falls back to asking a child process when the KFD
+    sysfs tree is absent (the child touches HIP and exits; this process still does not)."""
+    nodes = glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')
+    if not nodes:
+        try:
+            out = subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'],
+                                 capture_output=True, text=True, timeout=300).stdout.split()
+            return int(out[-1]) if out else 0
+        except (OSError, ValueError, subprocess.TimeoutExpired):
+            return 0
+    n = 0
+    for path in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(path).read().splitlines() if len(line.split()) >= 2)
+        except OSError:
+            continue            # a node of another container's GPU: not readable = not ours
+        if int(props.get('simd_count', '0')) == 0:
+            continue            # CPU node
+        minor = props.get('drm_render_minor')
+        dev = f'/dev/dri/renderD{minor}'
+        if minor is None or not os.access(dev, os.R_OK | os.W_OK):
+            continue            # present on the host, not handed to this container
+        n += 1
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(',') if x.strip() != '']))
+    return n
+
+
 def spawn_ranks(args):
     """Bare ``python bench.py --gpus N``: become the launcher of N ranks.  Nothing here initialises
-    a GPU (device_count() does not on this image); the ranks are fresh child processes."""
+    a GPU (devices are counted from sysfs: visible_gpu_count); the ranks are fresh child processes."""
     backend = os.environ.get('MT355_BENCH_BACKEND', 'nccl')
-    have = torch.cuda.device_count()
+    have = visible_gpu_count()
     if backend == 'nccl' and have < args.gpus:
         print(f'bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible', file=sys.stderr)
         sys.exit(2)

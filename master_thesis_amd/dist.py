@@ -96,13 +96,33 @@ def init_comm(device=None):
         return None
     device = torch.device(device if device is not None else ('cuda', torch.cuda.current_device()))
     rank, world = dist.get_rank(), dist.get_world_size()
-    try:
-        box = [RcclComm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        _comm = RcclComm(box[0], rank, world, device)
-    except Exception as e:       # noqa: BLE001 - every rank must end up on the SAME transport
-        _comm_failed = repr(e)
-        print(f'[mt355] rank {rank}: RCCL communicator unavailable ({e}); using torch.distributed', file=sys.stderr, flush=True)
+    # Every rank runs the SAME sequence of bootstrap collectives whatever fails locally:
+    # (1) all-gather of (host, device uuid / index): RCCL refuses two ranks on one device, so that case is
+    #     detected here instead of by an init error; (2) broadcast of (id | None, error); (3) MIN over "my
+    #     communicator came up".  A rank that raised in between still takes part in the next collective.
+    me = (os.uname().nodename, _device_identity(device))
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me)
+    shared = len(set(everyone)) < world
+    box = [None, None]
+    if rank == 0 and not shared:
+        try:
+            box[0] = RcclComm.unique_id()
+        except Exception as e:   # noqa: BLE001 - reported to every rank through the broadcast below
+            box[1] = repr(e)
+    dist.broadcast_object_list(box, src=0)
+    if shared:
+        _comm_failed = 'several ranks share one device'
+    elif box[0] is None:
+        _comm_failed = f'rank 0 could not create an RCCL id: {box[1]}'
+    else:
+        try:
+            _comm = RcclComm(box[0], rank, world, device)
+        except Exception as e:   # noqa: BLE001 - every rank must end up on the SAME transport
+            _comm_failed = repr(e)
+    if _comm is None and (rank == 0 or (not shared and box[0] is not None)):
+        print(f'[mt355] rank {rank}: RCCL communicator not used ({_comm_failed}); using torch.distributed',
+              file=sys.stderr, flush=True)
     # one rank failing moves everybody to the fallback (a split transport would deadlock)
     ok = torch.tensor([1 if _comm is not None else 0], device=device if dist.get_backend() == 'nccl' else 'cpu')
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -110,6 +130,15 @@ def init_comm(device=None):
         _comm.destroy()
         _comm, _comm_failed = None, 'another rank failed'
     return _comm
+
+
+def _device_identity(device):
+    """Something two ranks share exactly when they sit on the same card (uuid when torch exposes it)."""
+    try:
+        return str(torch.cuda.get_device_properties(device).uuid)
+    except Exception:            # noqa: BLE001 - older builds have no uuid field
+        vis = os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('CUDA_VISIBLE_DEVICES', ''))
+        return f'{vis}#{torch.device(device).index}'
 
 
 def transport():

@@ -130,28 +130,43 @@ class FlatAdam(torch.optim.Optimizer):
         """Accepts FlatAdam's own layout and the ``torch.optim.Adam`` layout of reference /
         Lightning checkpoints (``state`` = {index: {step, exp_avg, exp_avg_sq}} over the same
         parameter order, ``param_groups``).  The device-resident {step, lr} follow."""
+        for s in sd['param_groups']:
+            # the fused kernel is plain Adam (model_dfpn.py:302, model_chn.py:385): refuse a state written for another rule
+            if s.get('weight_decay', 0) or s.get('amsgrad', False) or s.get('maximize', False):
+                raise ValueError('checkpoint optimizer uses weight_decay / amsgrad / maximize '
+                                 f'({ {k: s.get(k) for k in ("weight_decay", "amsgrad", "maximize")} }): '
+                                 'FlatAdam implements plain Adam only')
         if 'state' in sd and 'exp_avg' not in sd:
+            # torch.optim.Adam numbers the state by position in ITS parameter list.  The reference hands Adam
+            # self.parameters() (model_dfpn.py:302), where the frozen VGG tensors sit between the SeparableConv4d and the
+            # mixer parameters (model_dfpn.py:32,487-488) and never get state: the k-th STATEFUL parameter of the
+            # checkpoint is the k-th trainable parameter here, whatever its index.
             st = sd['state']
-            if len(st) not in (0, len(self._plist)):
-                raise ValueError(f'optimizer state holds {len(st)} parameters, this model trains {len(self._plist)}: '
-                                 'the checkpoint was written for a different set of trainable parameters '
-                                 '(the reference also hands the frozen VGG / aligner to Adam)')
-            steps = set()
-            for i, (off, k) in enumerate(self._slices):
-                ent = st.get(i, st.get(str(i)))
-                if ent is None:
-                    continue
-                self.exp_avg[off:off + k].copy_(ent['exp_avg'].reshape(-1))
-                self.exp_avg_sq[off:off + k].copy_(ent['exp_avg_sq'].reshape(-1))
-                steps.add(int(ent['step']))
+            keys = sorted(st.keys(), key=int)
+            if len(keys) not in (0, len(self._plist)):
+                raise ValueError(f'optimizer state holds {len(keys)} parameters, this model trains {len(self._plist)}: '
+                                 'the checkpoint was written for a different set of trainable parameters')
+            ents = [st[k] for k in keys]
+            for n_, (ent, (off, k)) in enumerate(zip(ents, self._slices)):      # validate everything before copying anything
+                for name in ('exp_avg', 'exp_avg_sq'):
+                    if ent[name].numel() != k:
+                        raise ValueError(f'optimizer state entry {keys[n_]} ({name}: {ent[name].numel()} elements) does not '
+                                         f'fit trainable parameter {n_} ({k} elements, shape {tuple(self._plist[n_].shape)})')
+            steps = {int(ent['step']) for ent in ents}
             if len(steps) > 1:
                 raise ValueError(f'per-parameter step counts differ ({sorted(steps)}): one fused update needs one')
+            for ent, (off, k) in zip(ents, self._slices):
+                self.exp_avg[off:off + k].copy_(ent['exp_avg'].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(ent['exp_avg_sq'].reshape(-1))
             self.step_count = steps.pop() if steps else 0
         else:
+            if sd['exp_avg'].numel() != self.exp_avg.numel() or sd['exp_avg_sq'].numel() != self.exp_avg_sq.numel():
+                raise ValueError(f'flat optimizer state holds {sd["exp_avg"].numel()} elements, this model trains '
+                                 f'{self.exp_avg.numel()}')
             self.step_count = int(sd['step'])
             self.exp_avg.copy_(sd['exp_avg'])
             self.exp_avg_sq.copy_(sd['exp_avg_sq'])
         for g, s in zip(self.param_groups, sd['param_groups']):
-            g.update({k: v for k, v in s.items() if k != 'params'})
+            g.update({k: v for k, v in s.items() if k in ('lr', 'betas', 'eps', 'initial_lr')})
         self.sync_device_state()
         E.bump_weight_epoch()

@@ -207,6 +207,7 @@ def test_g12_inpainting_drivers(golden, chn_sd):
     (x, m), y, info = S.synthetic_batch(1, 4, 64, 64, seed=12)
     with torch.no_grad():
         close(O.inpaint_ff(chn_sd, x[0], m[0]), g['ff'], rtol=2e-3)
+        close(O.inpaint_ip(chn_sd, x[0], m[0]), g['ip'], rtol=2e-3)
         close(O.inpaint_cp(chn_sd, x[0], m[0], N=2), g['cp'], rtol=2e-3)
 
 
