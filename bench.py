@@ -62,6 +62,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-check', action='store_true', help='skip the GPU-vs-oracle loss check')
     ap.add_argument('--no-chn', action='store_true')
+    ap.add_argument('--no-dfpn', action='store_true', help='do not time the DFPN step (profiling runs of the CHN step alone)')
     ap.add_argument('--no-graph', action='store_true', help='eager launches instead of a captured hipGraph')
     ap.add_argument('--cpu-clips', type=int, default=1, help='clips of the batch the CPU baseline steps on')
     ap.add_argument('--cpu-steps', type=int, default=3, help='timed CPU steps (after one warm-up)')
@@ -148,6 +149,43 @@ def corr_roofline(b_pairs=2048):
             'tflops': flops / (ms * 1e-3) / 1e12}
 
 
+def warp_roofline(pairs=1024, size=256):
+    """Stand-alone warp (K9, FlowsUtils.align_set, utils.py:77-104) micro-benchmark: bilinear RGB + nearest
+    visibility in one launch on ``pairs`` (clip, reference) pairs at ``size``^2 -- 40*h*w bytes per pair
+    (read (3+1+2)*h*w*4, write (3+1)*h*w*4), >= 2 GB per launch so that the Infinity Cache
+    cannot hold it.  Flows are small random affine grids plus sub-pixel noise (the training distribution)."""
+    from master_thesis_amd import ops
+    import torch.nn.functional as F
+    b, r = pairs // 4, 4
+    g = torch.Generator(device='cpu').manual_seed(7)
+    x = torch.rand((b, 3, r, size, size), generator=g).cuda()
+    v = (torch.rand((b, 1, r, size, size), generator=g) > 0.1).float().cuda()
+    p = torch.rand((b * r, 4), generator=g) * 2 - 1
+    ang, sc = p[:, 0] * 0.2, 1 + p[:, 1] * 0.1
+    theta = torch.zeros((b * r, 2, 3))
+    theta[:, 0, 0], theta[:, 0, 1] = sc * torch.cos(ang), -sc * torch.sin(ang)
+    theta[:, 1, 0], theta[:, 1, 1] = sc * torch.sin(ang), sc * torch.cos(ang)
+    theta[:, :, 2] = p[:, 2:4] * (50.0 / (size / 2))
+    flow = F.affine_grid(theta, [b * r, 1, size, size], align_corners=True).reshape(b, r, size, size, 2).cuda()
+    flow = (flow + (torch.rand(flow.shape, device='cuda') - 0.5) * (2.0 / size)).contiguous()
+    with torch.no_grad():
+        for _ in range(5):
+            ops.align_set(x, v, flow)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        n = 20
+        for _ in range(n):
+            ops.align_set(x, v, flow)
+        e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    bytes_ = 40.0 * size * size * b * r
+    gbs = bytes_ / (ms * 1e-3) / 1e9
+    return {'kernel': 'warp_fwd_kernel (mt_warp_fwd)', 'pairs': b * r, 'size': size, 'ms': ms, 'bound': 'hbm',
+            'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
+            'bytes_per_launch': bytes_}
+
+
 def pmc_traffic(label):
     """HBM bytes per launch of the kernel ``label`` from the newest committed rocprofv3 PMC passes
     (profiles/rNN_pmc_hbm_traffic.txt: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 correction
@@ -165,8 +203,17 @@ def pmc_traffic(label):
         name, rest = row.rsplit('>', 1)
         if (name + '>').replace(' ', '').startswith(want.rstrip('>')):   # (the label may omit trailing template arguments)
             f = rest.strip(',').split(',')
-            return {'traffic': float(f[3]) * 1e6, 'traffic_unit': 'bytes/launch (PMC, (2*FETCH_SIZE+WRITE_SIZE)*1024)',
-                    'traffic_source': os.path.relpath(files[-1], ROOT), 'traffic_launches': int(f[0])}
+            out = {'traffic': float(f[3]) * 1e6, 'traffic_unit': 'bytes/launch (PMC, (2*FETCH_SIZE+WRITE_SIZE)*1024)',
+                   'traffic_source': os.path.relpath(files[-1], ROOT), 'traffic_launches': int(f[0])}
+            # a counter file older than the kernels it describes goes stale silently: say so
+            srcs = glob.glob(os.path.join(ROOT, 'master_thesis_amd', 'csrc', '*.hip')) + \
+                glob.glob(os.path.join(ROOT, 'master_thesis_amd', 'csrc', '*.h'))
+            newest = max(srcs, key=os.path.getmtime) if srcs else None
+            if newest and os.path.getmtime(newest) > os.path.getmtime(files[-1]):
+                out['traffic_stale'] = True
+                print(f'bench.py: WARNING {out["traffic_source"]} is older than {os.path.relpath(newest, ROOT)}: roofline.traffic '
+                      'describes an earlier build of the kernels (re-run tools/collect_profiles.sh)', file=sys.stderr)
+            return out
     return none
 
 
@@ -410,11 +457,17 @@ def run_rank(args):
         # all-reduce (side stream, event-ordered) and the Adam launch follow it
         g = GraphedTrainStep(model, opt, batch, include_optimizer=(world == 1))
 
-        def graphed():
+        def graphed(marks=None):
             g.step()
             if world > 1:
+                if marks is not None:
+                    marks[0].record()
                 mdist.sync_gradients(opt)
+                if marks is not None:
+                    marks[1].record()
                 opt.step()
+                if marks is not None:
+                    marks[2].record()
         return graphed, eager, opt
 
     def measure(model, kind):
@@ -423,6 +476,16 @@ def run_rank(args):
         res = {'value': frames_per_step * args.steps / dt, 'unit': 'frames/s', 'ms_per_step': dt / args.steps * 1e3}
         if named and args.config == 2:
             res['step_tflops'] = TFLOP_PER_STEP[kind] * world / (res['ms_per_step'] * 1e-3)
+        if world > 1 and not args.no_graph:
+            # where an N > 1 step spends its time besides forward + backward: HIP events on the launch stream around the
+            # gradient exchange (it runs on the communicator's side stream; the launch stream waits for its last bucket)
+            # and around the Adam launch, three extra steps, this rank
+            marks = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(3)]
+            for mk in marks:
+                step(mk)
+            torch.cuda.synchronize()
+            res['allreduce_ms_per_step'] = statistics.median(mk[0].elapsed_time(mk[1]) for mk in marks)
+            res['adam_ms_per_step'] = statistics.median(mk[1].elapsed_time(mk[2]) for mk in marks)
         if rank == 0:
             agg = kernel_profile(eager)
             res['conv_engine_ms_per_step'] = sum(a[1] for a in agg.values())
@@ -434,7 +497,9 @@ def run_rank(args):
         return res, opt
 
     results = {}
-    results['dfpn'], opt_d = measure(dfpn, 'dfpn')
+    opt_d = None
+    if not (args.no_dfpn and not args.no_chn):
+        results['dfpn'], opt_d = measure(dfpn, 'dfpn')
     chn = None
     if not args.no_chn:
         del opt_d
@@ -442,7 +507,7 @@ def run_rank(args):
         chn = mt.CHN(vgg, None, dfpn, **kw).to(dev)
         results['chn'], opt_c = measure(chn, 'chn')
 
-    head_kind = 'chn' if (args.config == 5 and 'chn' in results) else 'dfpn'
+    head_kind = 'chn' if ((args.config == 5 or 'dfpn' not in results) and 'chn' in results) else 'dfpn'
     head = results[head_kind]
     cfg_name = {('dfpn', 2): 'cfg2', ('chn', 2): 'cfg3', ('chn', 5): 'cfg5', ('dfpn', 5): 'cfg5-shape'}
     if world > 1:
@@ -467,6 +532,11 @@ def run_rank(args):
                        (mdist._comm.world if mdist._comm is not None else torch.distributed.get_world_size()),
                        'bytes_per_step': 4 * sum(p.numel() for p in (chn if head_kind == 'chn' else dfpn).trainable_parameters())},
     }
+    if 'allreduce_ms_per_step' in head:
+        out['collective']['ms_per_step'] = head['allreduce_ms_per_step']
+        out['collective']['adam_ms_per_step'] = head['adam_ms_per_step']
+        out['collective']['note'] = ('rank 0, median of 3 steps: HIP events on the launch stream around sync_gradients '
+                                     '(buckets on the side stream, event-ordered) and around the Adam launch that follows the graph')
     if 'step_tflops' in head:
         out['step_tflops'] = head['step_tflops']
 
@@ -478,13 +548,20 @@ def run_rank(args):
         # MFMA products issued per fp32 multiply-add by the kernel's arithmetic
         per = 3 if ('f16' in name or ',2,bf16' in name or name.endswith(',2>') or '_rb_' in name or 'wino' in name) else \
             (6 if 'split' in name or 'halo' in name else 1)
-        peak = PEAK_FP32_MFMA_TFLOPS if per == 1 else PEAK_16BIT_MFMA_TFLOPS / per
+        # 1-D Winograd F(2,3) (conv_halo_wino.hip) issues 2/3 of the direct form's products (F(2,5) kernels: 6/10):
+        # its ceiling in ALGORITHMIC FLOP/s is the MFMA peak / products x that saving, and frac against THAT is the
+        # fraction of the matrix pipe's peak the executed MFMAs use (frac must not be able to pass 1)
+        saving = 1.5 if 'wino' in name else 1.0
+        peak = PEAK_FP32_MFMA_TFLOPS if per == 1 else PEAK_16BIT_MFMA_TFLOPS / per * saving
+        note = ('achieved = ALGORITHMIC conv FLOP (2*N*H*W*Cin*Cout*k*k per launch) / kernel time (HIP events around every '
+                f'launch of one eager step); peak = dense 16-bit MFMA peak {PEAK_16BIT_MFMA_TFLOPS:.0f} TFLOP/s / {per} MFMA '
+                'products per fp32 multiply-add of this arithmetic' +
+                (f' x {saving} (Winograd F(2,3) executes 1/{saving} of the direct form\'s products): frac = executed MFMA '
+                 'FLOP/s over the dense peak' if saving != 1.0 else '')) if per > 1 else 'fp32-input MFMA'
         out['roofline'] = {'kernel': name, 'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s',
-                           'frac': ach / peak, **pmc_traffic(name),
-                           'note': f'achieved = algorithmic conv FLOP / kernel time (HIP events around every launch of '
-                                   f'one eager step); peak = dense 16-bit MFMA peak {PEAK_16BIT_MFMA_TFLOPS:.0f} TFLOP/s / '
-                                   f'{per} MFMA products per fp32 multiply-add of this arithmetic' if per > 1 else
-                                   'fp32-input MFMA',
+                           'frac': ach / peak, **pmc_traffic(name), 'note': note,
+                           'executed_mfma_tflops': ach * per / saving,
+                           'frac_of_direct_form_ceiling': ach / (peak / saving),
                            'launches_per_step': launches, 'avg_launch_ms': kms / launches,
                            'share_of_conv_engine_ms': kms / tot_ms}
         out['kernels'] = head['kernels']
@@ -494,6 +571,7 @@ def run_rank(args):
                 res = {k: v for k, v in res.items() if k != '_agg'}
                 out['chn_train_step' if kind == 'chn' else 'dfpn_train_step'] = {'workload': workload(kind), **res}
         out['roofline_corr'] = corr_roofline()
+        out['roofline_warp'] = warp_roofline()
 
     failed = False
     if rank == 0 and world == 1:

@@ -176,6 +176,10 @@ typedef struct {
   uint32_t skip_tiles; /* halo-tile path: bit (at * btiles + bt) set = the 64 x 64 channel tile (D channels
                           64*at.., G channels 64*bt..) is not wanted and its slab entries stay undefined (a
                           launch shared by several layers forms a block-triangular product); 0 = all */
+  int32_t d_terms;     /* two-term split precisions, stride-1 3x3 / 5x5 halo-tile path: 0 / 2 = both 16-bit terms of D
+                          (three partial products, fp32-grade); 1 = D's leading term only (two partial products: D
+                          rounded to 11 / 8 significant bits, independent rounding errors per pixel, ~1e-4 relative on
+                          a gradient summed over >= 10^5 pixels) -- a speed / accuracy choice of the caller */
 } mt_wgrad;
 
 int mt_wgrad_run(const mt_wgrad* d, void* stream);

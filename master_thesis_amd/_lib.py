@@ -35,7 +35,7 @@ class Wgrad(C.Structure):
     _fields_ = [('d', View), ('g', View), ('KH', i32), ('KW', i32),
                 ('stride', i32), ('pad', i32), ('ups', i32), ('splits', i32),
                 ('slabs', C.c_void_p), ('precision', i32), ('algo', i32), ('with_bias', i32),
-                ('d_amax', C.c_void_p), ('g_amax', C.c_void_p), ('skip_tiles', C.c_uint32)]
+                ('d_amax', C.c_void_p), ('g_amax', C.c_void_p), ('skip_tiles', C.c_uint32), ('d_terms', i32)]
 
 
 class WarpLayout(C.Structure):

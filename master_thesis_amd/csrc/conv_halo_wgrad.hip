@@ -208,7 +208,10 @@ struct WgBatch {
 };
 struct WgOne {};
 
-template <int KS, int KHB, int FMT, bool BATCH = false>
+// DT = 1 (mt_wgrad.d_terms): D enters with its LEADING 16-bit term only -- two partial products (D_hi G_hi, D_hi G_lo)
+// instead of three, no D_lo plane staged or read.  D then carries 11 (fp16) significant bits: rounding errors that are
+// independent from pixel to pixel, so a gradient summed over ~10^5 .. 10^6 pixels is off by ~1e-4 relative.
+template <int KS, int KHB, int FMT, bool BATCH = false, int DT = 2>
 __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split, int ntiles,
                                                          int with_bias, int kh_base,
                                                          std::conditional_t<BATCH, WgBatch, WgOne> tab) {
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
         bf16x4 parts[NS];
         split4f<NS, FMT, 1>(rd[S][i], scD, parts);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sD[s * PX * LD + px * LD + c]) = parts[s];
+        for (int s = 0; s < DT; ++s) *reinterpret_cast<bf16x4*>(&sD[s * PX * LD + px * LD + c]) = parts[s];
       }
 #pragma unroll
       for (int i = 0; i < RG; ++i) {
@@ -386,10 +389,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
         for (int s = 0; s < NS; ++s) fb[kw][s] = tr_frag(sG + s * GP * LD, b_off + (r * GW + kw) * LD, LD);
       if (r < TR) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) fa[r % KHB][s] = tr_frag(sD + s * PX * LD, a_off + r * 16 * LD, LD);
+        for (int s = 0; s < DT; ++s) fa[r % KHB][s] = tr_frag(sD + s * PX * LD, a_off + r * 16 * LD, LD);
         if (do_bias) {
 #pragma unroll
-          for (int s = NS - 1; s >= 0; --s) {
+          for (int s = DT - 1; s >= 0; --s) {
             if constexpr (FMT == 0) acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[r % KHB][s], ones, acc_bias, 0, 0, 0);
             else acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[r % KHB][s]), __builtin_bit_cast(half8, ones), acc_bias, 0, 0, 0);
           }
@@ -400,7 +403,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
         const int ks = r - kh;                 // pixel row this patch row feeds through kernel row kh
         if (ks >= 0 && ks < TR) {
 #pragma unroll
-          for (int kw = 0; kw < KS; ++kw) mfma_splitf<NS, FMT>(fa[ks % KHB], fb[kw], acc[kh * KS + kw]);
+          for (int kw = 0; kw < KS; ++kw) {
+            if constexpr (DT == 2) {
+              mfma_splitf<NS, FMT>(fa[ks % KHB], fb[kw], acc[kh * KS + kw]);
+            } else if constexpr (FMT == 0) {
+              acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks % KHB][0], fb[kw][1], acc[kh * KS + kw], 0, 0, 0);
+              acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks % KHB][0], fb[kw][0], acc[kh * KS + kw], 0, 0, 0);
+            } else {
+              const half8 a0 = __builtin_bit_cast(half8, fa[ks % KHB][0]);
+              acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, __builtin_bit_cast(half8, fb[kw][1]), acc[kh * KS + kw], 0, 0, 0);
+              acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, __builtin_bit_cast(half8, fb[kw][0]), acc[kh * KS + kw], 0, 0, 0);
+            }
+          }
         }
       }
     }
@@ -673,7 +687,8 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
 #define MT_WGH2(KS, KHB, FMT, GRID, KH_BASE) \
   hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
 #define MT_WGPC(KS, KHB, FMT, KH_BASE) \
-  hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{})
+  do { if (d->d_terms == 1) hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT, false, 1>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); \
+       else hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); } while (0)
   // 16 gathered channels (and no up-sampled gather): four taps share a B tile (MT355_WGRAD_THIN=0: the kernel below)
   static const bool thin_on = [] { const char* e = getenv("MT355_WGRAD_THIN"); return !(e && e[0] == '0'); }();
   if (pc && thin_on && d->g.C == 16 && d->ups == 0 && !d->skip_tiles) {
@@ -753,7 +768,7 @@ extern "C" int mt_wgrad_run_batch(const mt_wgrad* descs, int32_t n, void* stream
                       e->g.sh == d->g.sh && e->g.sw == d->g.sw && e->g.n_in == d->g.n_in && e->g.sg == d->g.sg &&
                       e->KH == d->KH && e->KW == d->KW && e->stride == d->stride && e->pad == d->pad && e->ups == d->ups &&
                       e->splits == d->splits && e->precision == d->precision && e->algo == d->algo &&
-                      e->with_bias == d->with_bias && e->skip_tiles == d->skip_tiles;
+                      e->with_bias == d->with_bias && e->skip_tiles == d->skip_tiles && e->d_terms == d->d_terms;
     MT_REQUIRE(same, "mt_wgrad_run_batch: problem %d differs from problem 0 in geometry", i);
     MT_REQUIRE(e->d.p && e->g.p && e->slabs && (reinterpret_cast<uintptr_t>(e->d.p) & 15) == 0 && (reinterpret_cast<uintptr_t>(e->g.p) & 15) == 0,
                "mt_wgrad_run_batch: problem %d: null / unaligned pointers", i);
@@ -774,8 +789,12 @@ extern "C" int mt_wgrad_run_batch(const mt_wgrad* descs, int32_t n, void* stream
   const int tps = (ntiles + d->splits - 1) / d->splits;
   const dim3 grid(k.atiles * k.btiles, d->splits, n);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (prec == MT_PREC_F16X3)
+  if (prec == MT_PREC_F16X3 && d->d_terms == 1)
+    hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, true, 1>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
+  else if (prec == MT_PREC_F16X3)
     hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, true>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
+  else if (d->d_terms == 1)
+    hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 0, true, 1>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
   else
     hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 0, true>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
   return mt_check_launch("mt_wgrad_run_batch");

@@ -90,6 +90,9 @@ HALO_RB = os.environ.get('MT355_HALO_RB', '1') != '0'     # mirrors halo_rb_want
 WGRAD_PC = os.environ.get('MT355_WGRAD_PC', '1') != '0'   # mirrors wgrad_pc() in conv_halo_wgrad.hip
 WGRAD_PC5 = os.environ.get('MT355_WGRAD_PC5', '1') != '0'  # 5x5 on the producer / consumer kernel too (kernel rows 2 + 2 + 1)
 WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '512'))
+# 16-bit terms of dY that enter a weight gradient on the producer / consumer kernel (mt_wgrad.d_terms): 2 = both
+# (three partial products, fp32-grade); 1 = the leading term only (two products: dY rounded to 11 bits per pixel)
+WGRAD_D_TERMS = int(os.environ.get('MT355_WGRAD_D_TERMS', '2'))
 HALO_RB32 = os.environ.get('MT355_HALO_RB32', '0') == '1'  # mirrors halo_rb32_wanted() in conv_halo.hip (off by default)
 HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_enabled() in conv_halo_wino.hip
 TINY_OUT = os.environ.get('MT355_TINY_OUT', '1') != '0'   # ... and for 128 -> 1 / 2 channel layers (A/B switch)
@@ -720,7 +723,7 @@ class WgradBatch:
 
     def add(self, d, keep, finish, blocks, ntiles, slab_floats, kname, flops):
         key = (d.d.N, d.d.H, d.d.W, d.d.C, d.d.sn, d.d.sh, d.d.sw, d.d.n_in, d.d.sg, d.g.C, d.g.sn, d.g.sh, d.g.sw,
-               d.g.n_in, d.g.sg, d.precision, d.with_bias, d.skip_tiles)
+               d.g.n_in, d.g.sg, d.precision, d.with_bias, d.skip_tiles, d.d_terms)
         self.items.append((key, d, keep, finish, blocks, ntiles, slab_floats, kname, flops))
 
     def flush(self):
@@ -807,6 +810,7 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
                       and os.environ.get('MT355_WGRAD3_TALL', '1') != '0') else 4
         ntiles = dv.N * ((dv.H + trows - 1) // trows) * ((dv.W + 15) // 16)
         want = WGRAD_PC_BLOCKS if pc else 512        # blocks in flight: one 512-thread block per CU for pc
+        d.d_terms = WGRAD_D_TERMS if pc else 0
         d.splits = max(1, min((want + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 256))
     else:
         d.splits = _splits(tiles * t, pixels)

@@ -120,3 +120,65 @@ def test_graph_replay_equals_eager_at_benchmark_size():
         loss_g = g.step()
     np.testing.assert_allclose(float(loss_g), loss_e, rtol=1e-5)
     assert float((g_e - o_g.flat_g).norm() / g_e.norm()) < 1e-4
+
+
+def _slice_batch(batch, n):
+    (x, m), y, info = batch
+    cut = lambda t: t[:n].contiguous() if torch.is_tensor(t) else t[:n]       # noqa: E731
+    return (cut(x), cut(m)), cut(y), tuple(cut(i) for i in info)
+
+
+@pytest.mark.parametrize('kind', ['dfpn', 'chn'])
+def test_gradients_at_benchmark_geometry(kind):
+    """The backward kernels at the geometry bench.py times, against the oracle's autograd: two clips of the
+    benchmarked batch (frames_n = 5 => R = 4 group addressing in SeparableConv4d, a 2048-image batch there,
+    256 x 256 FlowEstimator / RRDBNet layers with dx_window and the batched dense-block weight gradients at
+    trunk size), the benchmark's weights, ``training_step().backward()`` into FlatAdam's flat gradient.
+    Ground truth = the oracle in fp64 (model_dfpn.py:135-158, model_chn.py:256-280); the criterion is
+    tests/_gradcheck.py's, with the relative L2 over all parameters held to 5e-4 outright (measured, three-product
+    arithmetic: HIP 5.5e-5 / 8.2e-5 for the DFPN / CHN step, the fp32 CPU oracle itself 5.2e-5 / 8.7e-5)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import master_thesis_amd as mt
+    from _gradcheck import check_grads_vs_fp64
+    from master_thesis_amd.synthetic import make_batch
+    torch.set_num_threads(bench.host_cores())
+    torch.manual_seed(0)
+    vgg = mt.VGGFeatures(device=DEV)
+    dfpn = mt.DFPN(vgg, **KW).to(DEV)
+    model = dfpn if kind == 'dfpn' else mt.CHN(vgg, None, dfpn, **KW).to(DEV)
+    gbatch = _slice_batch(make_batch(8, 5, 256, 256, DEV, seed=1234), 2)
+    opt = model.configure_optimizers()['optimizer']
+    opt.zero_grad()
+    loss = model.training_step(gbatch, 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    if kind == 'dfpn':
+        names = [k for k in sd if 'model_vgg' not in k and k not in ('mean', 'std')]
+        step = O.dfpn_training_step
+    else:
+        names = [k for k in sd if k.startswith('nn.')]
+        step = O.chn_training_step
+    assert len(names) == len(opt._plist)
+    tot_g, tot_c = check_grads_vs_fp64(model, step, sd, bench._cpu_batch(gbatch), names)
+    print(f'{kind}: relative L2 of the flat gradient vs the fp64 oracle: HIP {tot_g:.3e}, fp32 CPU oracle {tot_c:.3e}')
+    assert tot_g <= 5e-4, (tot_g, tot_c)
+
+
+def test_cfg5_full_batch_vs_oracle():
+    """BASELINE config 5 at ITS batch (batch 4, frames_n 7, 512 x 512; the bench's weights and make_batch seed):
+    every loss item of the DFPN and the CHN step within 1e-3 of the oracle."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import master_thesis_amd as mt
+    from master_thesis_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    vgg = mt.VGGFeatures(device=DEV)
+    dfpn = mt.DFPN(vgg, **KW).to(DEV)
+    chn = mt.CHN(vgg, None, dfpn, **KW).to(DEV)
+    batch = make_batch(4, 7, 512, 512, DEV, seed=1234)
+    for kind, model in (('dfpn', dfpn), ('chn', chn)):
+        res = bench.loss_check(kind, model, batch)
+        print(kind, res['rel_err'], f"oracle {res['oracle_seconds']} s")
+        assert res['ok'], (kind, res['rel_err'])

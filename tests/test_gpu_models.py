@@ -99,9 +99,11 @@ def test_g5_dfpn_forward_cfg1(golden, dfpn):
     assert_close(f16, g['flow_16'], what='flow_16')
     assert_close(f64, g['flow_64'], what='flow_64')
     assert_close(f, g['flow'], what='flow')
-    assert_close(xa, g['x_aligned'], tol=5e-3, what='x_aligned')
-    assert (va.cpu().numpy() != g['v_aligned']).mean() < 2e-3
-    assert (vmap.cpu().numpy() != g['v_map']).mean() < 2e-3
+    # measured (round 3): max-normalised error 4.6e-5, no pixel above 1e-4, no visibility pixel on the other side of
+    # a rounding tie on this clip -- so no tie / border allowance is needed at the 1e-3 bar
+    assert_close(xa, g['x_aligned'], tol=1e-3, what='x_aligned')
+    assert int((va.cpu().numpy() != g['v_aligned']).sum()) == 0
+    assert int((vmap.cpu().numpy() != g['v_map']).sum()) == 0
 
 
 def test_g6_dfpn_loss(golden, dfpn):
@@ -112,8 +114,9 @@ def test_g6_dfpn_loss(golden, dfpn):
             loss, items = dfpn._step(batch, 4)
         ref = g[f'{tag}.items']
         got = torch.stack([i.reshape(()) for i in items]).cpu().numpy()
-        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=1e-6, err_msg=tag)
-        np.testing.assert_allclose(float(loss), float(g[f'{tag}.loss'].reshape(-1)[0]), rtol=2e-3)
+        # (measured: 4e-7 relative on every item; the bar is 1e-3)
+        np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-7, err_msg=tag)
+        np.testing.assert_allclose(float(loss), float(g[f'{tag}.loss'].reshape(-1)[0]), rtol=1e-4)
 
 
 def test_g7_rrdbnet(golden, chn):
@@ -149,11 +152,12 @@ def test_g9_dfpn_training_step_grads(golden, mt, dfpn_sd):
     loss.backward()
     names = [k[len('dfpn.norm/'):] for k in g.files if k.startswith('dfpn.norm/')]
     assert len(names) == 2 * (6 + 14 + 21 + 21)
-    # norms against the reference's own (golden) gradients, loosely: see below
+    # norms against the reference's own (golden, fp32) gradients: both sides carry kink-flip noise (see
+    # _gradcheck.py); measured worst tensor 5e-4, median 7e-5
     params = dict(model.named_parameters())
     for n in names:
         ref = float(g[f'dfpn.norm/{n}'])
-        assert abs(float(params[n].grad.norm()) - ref) <= 5e-2 * ref + 1e-7, n
+        assert abs(float(params[n].grad.norm()) - ref) <= 5e-3 * ref + 1e-7, n
     _check_grads_vs_fp64(model, O.dfpn_training_step, dfpn_sd, batch, names)
     assert all(p.grad is None for n, p in model.named_parameters() if 'model_vgg' in n)
 
@@ -171,9 +175,9 @@ def test_g9_chn_training_step_grads(golden, mt, chn_sd):
     names = [k[len('chn.norm/'):] for k in g.files if k.startswith('chn.norm/')]
     assert len(names) == 2 * (5 + 300 + 5)
     params = dict(model.named_parameters())
-    for n in names:
+    for n in names:      # (measured: worst tensor 3.4e-3 -- one 32-element bias at a 16 x 16 trunk --, median 2e-7)
         ref = float(g[f'chn.norm/{n}'])
-        assert abs(float(params[n].grad.norm()) - ref) <= 5e-2 * ref + 1e-7, n
+        assert abs(float(params[n].grad.norm()) - ref) <= 1e-2 * ref + 1e-7, n
     _check_grads_vs_fp64(model, O.chn_training_step, chn_sd, batch, names)
     assert all(p.grad is None for n, p in model.named_parameters() if not n.startswith('nn.'))
 
@@ -189,7 +193,9 @@ def test_chn_step_multi_reference_vs_oracle(mt, chn_sd):
     with torch.no_grad():
         ref_loss, ref_items = O.chn_training_step(chn_sd, batch)
         loss, items = model._step(to_dev(batch))
-    np.testing.assert_allclose(torch.stack(items).cpu().numpy(), torch.stack(ref_items).numpy(), rtol=2e-3)
+    # (measured: 2e-6 relative; loss_nvh is exactly 0 on this clip)
+    np.testing.assert_allclose(torch.stack(items).cpu().numpy(), torch.stack(ref_items).numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(float(loss), float(ref_loss), rtol=1e-4)
 
 
 def test_optimizer_step_moves_loss(mt, dfpn_sd):
