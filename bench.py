@@ -47,7 +47,9 @@ def arithmetic_label():
     from master_thesis_amd import engine as E
     return (f'fp32 tensors; conv MFMA arithmetic {E.PRECISION} '
             f'({"2-term fp16 split of power-of-two scaled operands, 3 f16 MFMA per product, ~7e-8 rel" if E.PRECISION == "f16x3" else E.PRECISION}), '
-            f'{E.vgg_precision()} on the never-differentiated VGG passes; fp32 accumulation everywhere')
+            f'{E.vgg_precision()} on the never-differentiated VGG passes; weight gradients of the stride-1 3x3 / 5x5 layers: '
+            f'{"dY with its leading fp16 term, 2 products (gradient vs the fp64 oracle unchanged: tests/test_gpu_fullsize.py)" if E.WGRAD_D_TERMS == 1 else "both terms of dY, 3 products"}; '
+            'fp32 accumulation everywhere')
 
 
 def parse():

@@ -78,10 +78,13 @@ class RRDBNetFn(torch.autograd.Function):
                 E.absmax_into(window, amax)
 
         bufs = []
-        buf, buf_amax = new_buf(), E.new_amax(f0.device)
-        buf[..., :nf].copy_(f0)
-        track(buf[..., :nf], buf_amax)
-        for k in range(nb):
+        if RRDBNetFn._two_chains(n, f0):
+            buf, buf_amax, bufs = RRDBNetFn._trunk_forward_chains(f0, P, nf, gc, nb, conv, f16, keep)
+        else:
+            buf, buf_amax = new_buf(), E.new_amax(f0.device)
+            buf[..., :nf].copy_(f0)
+            track(buf[..., :nf], buf_amax)
+        for k in range(nb if bufs else 0, nb):      # (skipped when the two chains above ran the trunk)
             rrdb_x = buf[..., :nf]
             for j in (1, 2, 3):
                 key = f'rrdb_trunk.{k}.rdb{j}.'
@@ -108,6 +111,205 @@ class RRDBNetFn(torch.autograd.Function):
         if keep:
             saved = dict(first=first, bufs=bufs, z=buf, z_amax=buf_amax, y=y, u1=u1, u2=u2, hr=hr)
         return out, saved
+
+    # ---- the trunk as independent launch chains on several streams ------------------------------------------
+    # A dense-block launch at the trunk's size (32 images of 64 x 64 at cfg 3) is ONE wave of 1024 blocks that lives
+    # ~45 us: its ramp-up (every block first fetches its weight tile and halo) and its tail leave the matrix pipe idle
+    # for a third of the launch, and the next launch depends on it.  The images of a batch do not depend on one
+    # another, so the two halves of the batch run as two independent launch chains -- the second on a side stream,
+    # forked / joined with events (inside a captured step: two parallel branches of the graph) -- and one chain's
+    # ramp-up and tail overlap the other's main loop.  Every buffer the chains share is allocated before the fork
+    # and lives until after the join; every weight pack is touched (made, on first use) before the fork; each chain
+    # keeps its own running max|.| scalars, merged after the join for the launches that see the whole batch.
+    CHAINS = int(os.environ.get('MT355_RRDB_CHAINS', '2'))
+    _side = {}
+
+    @staticmethod
+    def _two_chains(n, t):
+        c = RRDBNetFn.CHAINS
+        return (c >= 2 and n % c == 0 and n >= c and t.is_cuda and E.USE_HALO and E.PRECISION != 'f32'
+                and E.PROFILE is None)
+
+    @staticmethod
+    def _chain_streams(device):
+        """(streams, image slices factory): chain 0 runs on the current stream, the others on side streams."""
+        c = RRDBNetFn.CHAINS
+        st = RRDBNetFn._side.setdefault(device, [])
+        while len(st) < c - 1:
+            st.append(torch.cuda.Stream(device=device))
+        return [torch.cuda.current_stream(device)] + st[:c - 1]
+
+    @staticmethod
+    def _fork(streams):
+        ev = torch.cuda.Event()
+        ev.record(streams[0])
+        for s_ in streams[1:]:
+            s_.wait_event(ev)
+
+    @staticmethod
+    def _join(streams):
+        for s_ in streams[1:]:
+            ev = torch.cuda.Event()
+            ev.record(s_)
+            streams[0].wait_event(ev)
+
+    @staticmethod
+    def _trunk_forward_chains(f0, P, nf, gc, nb, conv, f16, keep):
+        """The nb x 3 dense blocks (model_chn.py:558-623) on the two halves of the batch at once."""
+        n, h, w, _ = f0.shape
+        cw = nf + 4 * gc
+        dev = f0.device
+        streams = RRDBNetFn._chain_streams(dev)
+        nc = len(streams)
+        nbuf = 3 * nb + 1
+        # every buffer up front (main stream); without a backward to feed, four rotate (an RRDB's input is read
+        # again by the residual after its third block)
+        pool = [torch.empty((n, h, w, cw), device=dev, dtype=torch.float32) for _ in range(nbuf if keep else 4)]
+        amax = [torch.zeros((nbuf,), device=dev, dtype=torch.float32) for _ in range(nc)] if f16 else [None] * nc
+        halves = [slice(c * (n // nc), (c + 1) * (n // nc)) for c in range(nc)]
+        # touch every weight pack on the main stream (first use makes it: the chains must only ever read them)
+        prec = E.eff_precision(True)
+        for k in range(nb):
+            for j in (1, 2, 3):
+                for i in range(1, 6):
+                    E._pack(P[f'rrdb_trunk.{k}.rdb{j}.conv{i}.weight'], 0, 'f', prec, halo=True)
+        pool[0][..., :nf].copy_(f0)
+        RRDBNetFn._fork(streams)
+
+        def a_(c, i):
+            return amax[c][i:i + 1] if f16 else None
+
+        def rdb(c, k, j, idx):
+            sl = halves[c]
+            buf, nxt = pool[idx % len(pool)][sl], pool[(idx + 1) % len(pool)][sl]
+            key = f'rrdb_trunk.{k}.rdb{j}.'
+            for i in range(1, 5):
+                conv(f'{key}conv{i}', buf[..., :nf + (i - 1) * gc], nf + (i - 1) * gc, gc, act=LRELU,
+                     out=buf[..., nf + (i - 1) * gc: nf + i * gc], x_amax=a_(c, idx), y_amax=a_(c, idx))
+            conv(f'{key}conv5', buf, cw, nf, out=nxt[..., :nf], res=buf[..., :nf], alpha=0.2, beta=1.0,
+                 x_amax=a_(c, idx), y_amax=a_(c, idx + 1))
+
+        for c in range(nc):
+            with torch.cuda.stream(streams[c]):
+                if f16:
+                    E.absmax_into(pool[0][halves[c]][..., :nf], a_(c, 0))
+        idx = 0
+        for k in range(nb):
+            for j in (1, 2, 3):
+                for c in range(nc):        # (alternating, so that eager launches of all chains arrive together)
+                    with torch.cuda.stream(streams[c]):
+                        rdb(c, k, j, idx)
+                idx += 1
+            for c in range(nc):
+                with torch.cuda.stream(streams[c]):
+                    cur = pool[idx % len(pool)][halves[c]][..., :nf]
+                    rrdb_x = pool[(idx - 3) % len(pool)][halves[c]][..., :nf]
+                    _axpby(cur, 0.2, rrdb_x, 1.0, cur)              # 0.2 * y + x  (:585)
+                    if f16:
+                        E.absmax_into(cur, a_(c, idx))
+        RRDBNetFn._join(streams)
+        merged = torch.stack(amax).amax(0) if f16 else None
+        bufs = [(pool[i], merged[i:i + 1] if f16 else None) for i in range(nbuf - 1)] if keep else [None]
+        last = pool[(nbuf - 1) % len(pool)]
+        return last, (merged[nbuf - 1: nbuf] if f16 else None), bufs
+
+    @staticmethod
+    def _trunk_backward_chains(P, G, bufs, dcur, nf, gc, nb, f16, wbatch):
+        """Backward of the nb x 3 dense blocks in gather form (see _rdb_backward_gather) as two chains over the two
+        halves of the batch; the weight gradients see the whole batch and are recorded into ``wbatch`` (launched by
+        the caller after the chains have joined).  Returns the gradient wrt the trunk input."""
+        n, h, w, _ = dcur.shape
+        cw = nf + 4 * gc
+        dev = dcur.device
+        streams = RRDBNetFn._chain_streams(dev)
+        nc = len(streams)
+        halves = [slice(c * (n // nc), (c + 1) * (n // nc)) for c in range(nc)]
+        nblk = 3 * nb
+        prec = E.eff_precision(True)
+        # -- before the fork, on the main stream: buffers, scale scalars, weight packs
+        dzbs = [torch.empty((n, h, w, cw), device=dev, dtype=torch.float32) for _ in range(nblk)]
+        douts = [torch.empty((n, h, w, nf), device=dev, dtype=torch.float32) for _ in range(nb)]   # grad wrt each RRDB's input
+        dins = [torch.empty((n, h, w, nf), device=dev, dtype=torch.float32) for _ in range(nb)]    # ... wrt its rdb1's input
+        dba = [torch.zeros((nblk,), device=dev, dtype=torch.float32) for _ in range(nc)] if f16 else [None] * nc
+        dba_all = torch.empty((nblk,), device=dev, dtype=torch.float32) if f16 else None           # max over all chains
+        packs = {}
+        for k in range(nb):
+            for j in (1, 2, 3):
+                key = f'rrdb_trunk.{k}.rdb{j}.'
+                W = [None] + [P[f'{key}conv{i}.weight'] for i in (1, 2, 3, 4, 5)]
+                wa = E.stack_amax(W[1:]) if prec == 'f16x3' else None
+                packs[key] = ([None] + [E.pack_stacked_bwd([W[l] for l in range(5, i, -1)], nf + (i - 1) * gc, gc, prec, wa)
+                                        for i in (1, 2, 3, 4)],
+                              E.pack_stacked_bwd([W[l] for l in (5, 4, 3, 2, 1)], 0, nf, prec, wa))
+
+        def spec(cin, cout):
+            return E.LayerSpec('c', cin, cout, 3, 1, NONE, 0)
+
+        def a_(c, i):
+            return dba[c][i:i + 1] if f16 else None
+
+        def chain_rdb(c, key, buf, bidx, last):
+            """The five gather launches of one dense block on half ``c``.  ``last``: None = write 0.2 * d_in into the
+            dz5 window of the block that runs next (bidx + 1); else the tensor that takes d_in = dense + 5 dz5."""
+            sl = halves[c]
+            dzb, bufc = dzbs[bidx][sl], buf[sl]
+            pk, pk_in = packs[key]
+            for i in (4, 3, 2, 1):
+                kk = nf + (4 - i) * gc
+                c0 = nf + (i - 1) * gc
+                E.conv_backward_data(spec(gc, kk), dzb[..., :kk], None, E.view_of(dzb[..., kk: kk + gc]),
+                                     dsrc=bufc[..., c0: c0 + gc], dact=LRELU, dz_amax=a_(c, bidx), y_amax=a_(c, bidx),
+                                     packed=pk[i])
+            if last is None:
+                E.conv_backward_data(spec(nf, cw), dzb, None, E.view_of(dzbs[bidx + 1][sl][..., :nf]), dz_amax=a_(c, bidx),
+                                     packed=pk_in, alpha=0.2, res=dzb[..., :nf], beta=1.0, y_amax=a_(c, bidx + 1))
+            else:
+                E.conv_backward_data(spec(nf, cw), dzb, None, E.view_of(last[sl]), dz_amax=a_(c, bidx), packed=pk_in,
+                                     res=dzb[..., :nf], beta=5.0, y_amax=E.new_amax(dev) if f16 else None)
+
+        RRDBNetFn._fork(streams)
+        bidx = 0                                     # blocks in backward order: (nb-1, rdb3), (nb-1, rdb2), ...
+        order = []
+        for k in range(nb - 1, -1, -1):
+            drr = dcur if k == nb - 1 else douts[k + 1]
+            for c in range(nc):
+                with torch.cuda.stream(streams[c]):
+                    sl = halves[c]
+                    # rdb3: dz5 = 0.2 * (0.2 * drr); rdb2 / rdb1 get theirs from the launch that ends the block before
+                    _axpby(drr[sl], 0.04, drr[sl], 0.0, dzbs[bidx][sl][..., :nf])
+                    if f16:
+                        E.absmax_into(dzbs[bidx][sl][..., :nf], a_(c, bidx))
+            for j in (3, 2, 1):
+                key = f'rrdb_trunk.{k}.rdb{j}.'
+                buf, buf_amax = bufs[3 * k + (j - 1)]
+                for c in range(nc):
+                    with torch.cuda.stream(streams[c]):
+                        chain_rdb(c, key, buf, bidx, None if j > 1 else dins[k])
+                order.append((key, buf, buf_amax, bidx))
+                bidx += 1
+            for c in range(nc):
+                with torch.cuda.stream(streams[c]):
+                    sl = halves[c]
+                    _axpby(dins[k][sl], 1.0, drr[sl], 1.0, douts[k][sl])       # RRDB: out = 0.2 * y3 + x
+        RRDBNetFn._join(streams)
+        # -- after the join: the weight gradients of every block over the whole batch (recorded; the caller flushes)
+        if f16:
+            torch.amax(torch.stack(dba), 0, out=dba_all)
+        for key, buf, buf_amax, b in order:
+            dzb = dzbs[b]
+            da = dba_all[b:b + 1] if f16 else None
+            W = [None] + [P[f'{key}conv{i}.weight'] for i in (1, 2, 3, 4, 5)]
+            Bi = [None] + [P[f'{key}conv{i}.bias'] for i in (1, 2, 3, 4, 5)]
+            dw, db = E.conv_backward_weight(spec(cw, nf), dzb[..., :nf], E.view_of(buf), W[5], x_amax=buf_amax, dz_amax=da,
+                                            grad_w=E.inplace_grad(W[5]), grad_b=E.inplace_grad(Bi[5]), defer=wbatch)
+            G[f'{key}conv5.weight'], G[f'{key}conv5.bias'] = dw, db
+            subs = [((4 - i) * gc, gc, nf + (i - 1) * gc, W[i], E.inplace_grad(W[i]), E.inplace_grad(Bi[i]))
+                    for i in (1, 2, 3, 4)]
+            res = E.conv_backward_weight(spec(nf + 3 * gc, 4 * gc), dzb[..., nf: cw], E.view_of(buf[..., :nf + 3 * gc]), W[1],
+                                         x_amax=buf_amax, dz_amax=da, sub_blocks=subs, defer=wbatch)
+            for i, (dwi, dbi) in zip((1, 2, 3, 4), res):
+                G[f'{key}conv{i}.weight'], G[f'{key}conv{i}.bias'] = dwi, dbi
+        return douts[0]
 
     @staticmethod
     def _rdb_backward_gather(key, P, G, buf, buf_amax, dzb, dba, nf, gc, f16, nxt=None, defer=None):
@@ -224,6 +426,9 @@ class RRDBNetFn(torch.autograd.Function):
         # (3 nb x 100 MB at B = 8, 256^2: the card has 288 GB).  MT355_RDB_WGRAD_BATCH=0: one launch per block.
         wbatch = E.WgradBatch() if gather and os.environ.get('MT355_RDB_WGRAD_BATCH', '1') != '0' else None
         bufs = S['bufs']
+        if gather and wbatch is not None and fused_dz5 and RRDBNetFn._two_chains(n, dy):
+            dcur = RRDBNetFn._trunk_backward_chains(P, G, bufs, dcur, nf, gc, nb, f16, wbatch)
+            nb = 0            # (the loop below is skipped)
         for k in range(nb - 1, -1, -1):
             drr = dcur                                        # grad wrt this RRDB's output
             d_rdb, s_rdb = drr, 0.2                           # grad wrt rdb3's output = 0.2 * drr

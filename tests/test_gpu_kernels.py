@@ -183,6 +183,38 @@ def test_conv3x3_f16x3_is_fp32_grade(mt, case):
     assert e_fwd < 3e-6 and e_bwd < 3e-6, (e_fwd, e_bwd, e_ref)
 
 
+@pytest.mark.parametrize('case', [(4, 64, 64, 128, 128, 3), (4, 64, 64, 128, 128, 5), (64, 16, 16, 256, 256, 3)])
+def test_weight_gradient_terms(mt, case):
+    """mt_wgrad.d_terms on the producer / consumer weight-gradient kernel against an fp64 reference, on the worst
+    case for it -- a gradient that is a sum of pure noise (heavy-tailed dY with random signs, so nothing of a term's
+    rounding error averages against signal): both 16-bit terms of dY = fp32 grade (measured 2.8e-7 relative L2); the
+    leading term only (two partial products, the training default) = 2.1e-4."""
+    from master_thesis_amd import engine as E
+    n, h, w, cin, cout, k = case
+    spec = E.LayerSpec('c', cin, cout, k, 1, 1)
+    tag = 'wgterms.' + '.'.join(map(str, case))
+    x = S.uniform(tag + '.x', (n, h, w, cin), -1, 1)
+    dz = S.uniform(tag + '.dz', (n, h, w, cout), -1, 1) * torch.exp(4 * S.uniform(tag + '.m', (n, h, w, cout), -1, 1))
+    wt = torch.zeros((cout, cin, k, k))
+    wr = wt.double().requires_grad_(True)
+    y = F.conv2d(x.permute(0, 3, 1, 2).double(), wr, None, padding=k // 2)
+    ref, = torch.autograd.grad(y, wr, dz.permute(0, 3, 1, 2).double())
+    ref_b = dz.double().sum((0, 1, 2))
+    old = E.WGRAD_D_TERMS
+    try:
+        with E.precision('f16x3'):
+            for terms, bound in ((2, 3e-6), (1, 5e-4)):
+                E.WGRAD_D_TERMS = terms
+                dw, db = E.conv_backward_weight(spec, dz.to(dev()), E.view_of(x.to(dev())), wt.to(dev()))
+                e = float((dw.double().cpu() - ref).norm() / ref.norm())
+                eb = float((db.double().cpu() - ref_b).norm() / ref_b.norm())
+                assert e < bound and eb < bound, (terms, e, eb)
+                if terms == 1:
+                    assert e > 2e-5, 'the two-product kernel did not run'
+    finally:
+        E.WGRAD_D_TERMS = old
+
+
 def test_tiny_exit_layer_gates_by_the_saved_activation(mt):
     """conv(64 -> 128, ReLU) -> conv(128 -> 2): the backward-data of the 2-channel exit runs on the fp32 VALU
     kernel and gates by ReLU'(saved output) in its epilogue (model_dfpn.py:708-710)."""
