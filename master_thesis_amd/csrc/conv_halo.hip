@@ -509,6 +509,10 @@ __host__ __device__ inline int halo_ck(int cin_p, int ns) { return (ns == 3 || (
 bool halo_wino_enabled();                                            // conv_halo_wino.hip
 bool halo_wino_mf16();
 void mt_halo_wino_launch(const void* convk, int fmt, void* stream);
+bool halo_wino25_wanted(int cin_p, int cout_p, int T);               // conv_halo_wino25.hip
+void mt_halo_wino25_launch(const void* convk, int fmt, void* stream);
+void mt_pack_halo_wino25_launch(const float* src, int A, int B, long sa, long sb, long st, void* dst, int nchunk, int ntile,
+                                int flip, const float* wamax, int nchunk_total, int ch_off, void* stream);
 namespace {
 // 1-D Winograd F(2,3) on the 3 x 3 layers the register-B kernel would take (T = 9 taps)
 bool halo_wino_wanted(int cin_p, int cout_p, int T) { return T == 9 && halo_rb_wanted(cin_p, cout_p) && halo_wino_enabled(); }
@@ -526,6 +530,10 @@ void launch_halo(const ConvK& k, hipStream_t s) {
       const int ty16 = (k.Ho + 15) / 16;
       hipLaunchKernelGGL((igemm_halo_rb32_kernel<FMT>), dim3((unsigned)k.N * ty16 * tiles_x, (k.Co + 31) / 32), dim3(256), 0, s, k,
                          ty16, tiles_x);
+      return;
+    }
+    if (KS == 5 && k.ups == 0 && halo_wino25_wanted(k.C, k.Co, 25)) {      // 1-D Winograd F(2,5), 128-wide tiles
+      mt_halo_wino25_launch(&k, FMT, s);
       return;
     }
     if (halo_rb_wanted(k.C, k.Co)) {
@@ -688,7 +696,9 @@ __global__ void weight_pack_jobs_kernel(const mt_pack_job* jobs) {
   const int BN = j.AP > 64 ? 128 : (j.AP > 32 ? 64 : 32);
   const int nchunk = (j.BP + CK - 1) / CK, ntile = (j.AP + BN - 1) / BN;
   const int nchunk_total = (j.BP_total + CK - 1) / CK, ch_off = j.b_off / CK;
-  if (j.frag_order == 2 || j.frag_order == 4)
+  if (j.frag_order == 5)
+    pack_halo_wino25_body(j.src, j.A, j.B, j.sa, j.sb, j.st, dst, nchunk, ntile, j.flip, j.w_amax, nchunk_total, ch_off);
+  else if (j.frag_order == 2 || j.frag_order == 4)
     pack_halo_wino_body(j.src, j.A, j.B, j.sa, j.sb, j.st, dst, nchunk, ntile, j.flip, j.w_amax, nchunk_total, ch_off, BN / 32,
                         j.frag_order == 4);
   else if (j.frag_order)
@@ -712,6 +722,7 @@ extern "C" int64_t mt_weight_pack_halo_elems(int32_t AP, int32_t BP, int32_t T, 
   const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = halo_ck(BP, NS), LD = CK + 8;
   const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);
   if (NS == 2 && halo_wino_wanted(BP, AP, T)) T = 12;      // the (ky, xi) "taps" of the Winograd image (fragment order)
+  else if (NS == 2 && halo_wino25_wanted(BP, AP, T)) T = 30;   // F(2,5): 5 kernel rows x 6 xi
   return (int64_t)T * ((BP + CK - 1) / CK) * ((AP + BN - 1) / BN) * NS * BN * LD;
 }
 
@@ -736,6 +747,10 @@ static int pack_halo_impl(const float* src, int32_t A, int32_t B, int32_t T, int
                        reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, w_amax, nchunk_total, ch_off, BN / 32,
                        (BN == 128 && halo_wino_mf16()) ? 1 : 0);
     return mt_check_launch("mt_weight_pack_halo(wino)");
+  }
+  if (NS == 2 && halo_wino25_wanted(BP_total, AP, T)) {   // F(2,5)-transformed fragments for igemm_wino25_kernel
+    mt_pack_halo_wino25_launch(src, A, B, (long)sa, (long)sb, (long)st, dst, nchunk, ntile, flip, w_amax, nchunk_total, ch_off, stream);
+    return mt_check_launch("mt_weight_pack_halo(wino25)");
   }
   if (NS == 2 && (halo_rb_wanted(BP_total, AP) || halo_rb32_wanted(BP_total, AP, T))) {     // fragment order for igemm_halo_rb(32)_kernel (fits the same buffer)
     const long tot = (long)T * nchunk * ntile * (BN / 32) * 1024;
@@ -767,6 +782,7 @@ extern "C" int mt_weight_pack_halo_part(const float* src, int32_t A, int32_t B, 
 extern "C" int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, int32_t T, int32_t precision) {
   if (precision == MT_PREC_BF16X6) return 0;
   if (halo_rb32_wanted(BP_total, AP, T)) return 3;
+  if (halo_wino25_wanted(BP_total, AP, T)) return 5;        // 5: F(2,5) fragments (igemm_wino25_kernel)
   if (!halo_rb_wanted(BP_total, AP)) return 0;
   if (!halo_wino_wanted(BP_total, AP, T)) return 1;
   return (AP > 64 && halo_wino_mf16()) ? 4 : 2;        // 4: Winograd fragments of v_mfma_f32_16x16x32 (128-wide tiles)

@@ -33,7 +33,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* base, int off, int ld) {
 // ST = 2: the gathered tensor is sampled with stride 2 (a stride-2 Conv2d, or a stride-2
 // ConvTranspose2d with the roles of input and output gradient swapped): the patch is
 // (TR-1)*2+KHB x (TW-1)*2+KS pixels and the k rows of a G fragment are every second pixel.
-template <int KS, int KHB, int NS, int FMT, int OCC, int ST = 1, int TRP = 4>
+// DT = 1: D enters with its leading 16-bit term only (mt_wgrad.d_terms, see wgrad_pc_kernel).
+template <int KS, int KHB, int NS, int FMT, int OCC, int ST = 1, int TRP = 4, int DT = NS>
 __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split,
                                                             int ntiles, int with_bias, int kh_base) {
   constexpr int TR = TRP, TW = 16, PX = TR * TW;         // pixel tile: TR (4 or 8) rows x 16
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
       split4f<NS, FMT>(rd[i], scD, parts);
       const int px = (tid + 256 * i) / (CH / 4);
 #pragma unroll
-      for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sD[s][px * LD + c4]) = parts[s];
+      for (int s = 0; s < DT; ++s) *reinterpret_cast<bf16x4*>(&sD[s][px * LD + c4]) = parts[s];
     }
 #pragma unroll
     for (int i = 0; i < RG; ++i) {
@@ -148,10 +149,10 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
     for (int ks = 0; ks < TR; ++ks) {
       bf16x8 fa[NS];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) fa[s] = tr_frag(sD[s], a_off + ks * 16 * LD, LD);
+      for (int s = 0; s < DT; ++s) fa[s] = tr_frag(sD[s], a_off + ks * 16 * LD, LD);
       if (do_bias) {
 #pragma unroll
-        for (int s = NS - 1; s >= 0; --s) {
+        for (int s = DT - 1; s >= 0; --s) {
           if constexpr (FMT == 0) acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], ones, acc_bias, 0, 0, 0);
           else acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[s]), __builtin_bit_cast(half8, ones), acc_bias, 0, 0, 0);
         }
@@ -163,7 +164,16 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
           bf16x8 fb[NS];
 #pragma unroll
           for (int s = 0; s < NS; ++s) fb[s] = tr_frag(sG[s], b_off + ((ks * ST + kh) * GW + kw) * LD, ST * LD);
-          mfma_splitf<NS, FMT>(fa, fb, acc[kh * KS + kw]);
+          if constexpr (DT == NS) {
+            mfma_splitf<NS, FMT>(fa, fb, acc[kh * KS + kw]);
+          } else if constexpr (FMT == 0) {
+            acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc[kh * KS + kw], 0, 0, 0);
+            acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc[kh * KS + kw], 0, 0, 0);
+          } else {
+            const half8 a0 = __builtin_bit_cast(half8, fa[0]);
+            acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, __builtin_bit_cast(half8, fb[1]), acc[kh * KS + kw], 0, 0, 0);
+            acc[kh * KS + kw] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, __builtin_bit_cast(half8, fb[0]), acc[kh * KS + kw], 0, 0, 0);
+          }
         }
     }
   }
@@ -685,7 +695,8 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
 #define MT_WGH(KS, KHB, NS, FMT, OCC, GRID, KH_BASE) \
   hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, NS, FMT, OCC>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
 #define MT_WGH2(KS, KHB, FMT, GRID, KH_BASE) \
-  hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
+  do { if (d->d_terms == 1) hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2, 4, 1>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE); \
+       else hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE); } while (0)
 #define MT_WGPC(KS, KHB, FMT, KH_BASE) \
   do { if (d->d_terms == 1) hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT, false, 1>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); \
        else hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); } while (0)

@@ -100,6 +100,7 @@ WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '512'))
 WGRAD_D_TERMS = int(os.environ.get('MT355_WGRAD_D_TERMS', '1'))
 HALO_RB32 = os.environ.get('MT355_HALO_RB32', '0') == '1'  # mirrors halo_rb32_wanted() in conv_halo.hip (off by default)
 HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_enabled() in conv_halo_wino.hip
+HALO_WINO25 = os.environ.get('MT355_WINO25', '1') != '0'  # mirrors halo_wino25_enabled() in conv_halo_wino25.hip
 TINY_OUT = os.environ.get('MT355_TINY_OUT', '1') != '0'   # ... and for 128 -> 1 / 2 channel layers (A/B switch)
 TINY = os.environ.get('MT355_TINY', '1') != '0'           # fp32 VALU kernels for layers with <= 4 channels on one side (conv_tiny.hip)
 
@@ -130,9 +131,12 @@ def _igemm_name(co, halo, prec, cin_p=0):
     return f'{base}<{cfg}{_KTAG[prec]}>'
 
 
-def _kname(template, k, co=0, ho=0):
+def _kname(template, k, co=0, ho=0, cin_p=0):
     """Profiling label of a register-B shape: the Winograd kernels take the 3 x 3 layers
-    (igemm_wino16_kernel: Cout > 64 and more than 8 output rows)."""
+    (igemm_wino16_kernel: Cout > 64 and more than 8 output rows) and, with 128-wide tiles and whole
+    32-channel chunks, the 5 x 5 ones (igemm_wino25_kernel)."""
+    if k == 5 and HALO_WINO25 and '{rbw}' in template and co > 64 and cin_p > 32 and cin_p % 32 == 0:
+        return 'igemm_wino25_kernel<%s>' % ('f16' if ',f16' in template else 'bf16')
     if '|{k}' in template:            # the 32-output-channel register-B kernel exists for 3 x 3 only
         if k == 3:
             return template.split('|')[0]
@@ -608,7 +612,7 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
     else:
         flops = 2.0 * n * h * w_ * spec.cin * spec.cout * spec.k * spec.k
     name = f'igemm_halo_planes_kernel<{spec.k},s2,{"t" if transposed else "c"}>' if planes else \
-        _kname(_igemm_name(d.y.C, halo, prec, xv.C), spec.k, d.y.C, d.y.H)
+        _kname(_igemm_name(d.y.C, halo, prec, xv.C), spec.k, d.y.C, d.y.H, xv.C if spec.ups == 0 else 0)
     with _Prof(name, flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
     return out
@@ -690,7 +694,7 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     side = d.x if spec.kind == 'c' else yv          # the conv's output side
     flops = 2.0 * side.N * side.H * side.W * spec.cin * spec.cout * spec.k * spec.k
     name = f'igemm_halo_planes_kernel<{spec.k},s2,{"t" if d.transposed else "c"}>' if planes else \
-        _kname(_igemm_name(yv.C, as_fwd, prec, dzv.C), spec.k, yv.C, yv.H)
+        _kname(_igemm_name(yv.C, as_fwd, prec, dzv.C), spec.k, yv.C, yv.H, dzv.C)
     with _Prof(name, flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
 
@@ -815,7 +819,7 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
                       and os.environ.get('MT355_WGRAD3_TALL', '1') != '0') else 4
         ntiles = dv.N * ((dv.H + trows - 1) // trows) * ((dv.W + 15) // 16)
         want = WGRAD_PC_BLOCKS if pc else 512        # blocks in flight: one 512-thread block per CU for pc
-        d.d_terms = WGRAD_D_TERMS if pc else 0
+        d.d_terms = WGRAD_D_TERMS if (pc or spec.stride == 2) else 0      # (the stride-2 gathers of the single-role kernel too)
         d.splits = max(1, min((want + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 256))
     else:
         d.splits = _splits(tiles * t, pixels)

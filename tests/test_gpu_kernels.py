@@ -80,6 +80,10 @@ CONV_CASES = [
     (2, 37, 21, 128, 2, 5, 1, 'c', 1),
     (1, 70, 13, 128, 1, 5, 1, 'c', 0),
     (3, 19, 30, 128, 2, 3, 1, 'c', 2),
+    # round 3: 1-D Winograd F(2,5) for the 5 x 5 layers with 128-wide tiles: two n-tiles, ragged 8 x 16 tiles, one-tile images
+    (1, 16, 16, 256, 256, 5, 1, 'c', 1),
+    (2, 40, 24, 128, 128, 5, 1, 'c', 2),
+    (1, 7, 37, 64, 128, 5, 1, 'c', 0),
 ]
 
 
@@ -213,6 +217,35 @@ def test_weight_gradient_terms(mt, case):
                     assert e > 2e-5, 'the two-product kernel did not run'
     finally:
         E.WGRAD_D_TERMS = old
+
+
+@pytest.mark.parametrize('case', [(2, 32, 32, 128, 128), (1, 24, 40, 64, 128), (1, 16, 16, 256, 256)])
+def test_conv5x5_f16x3_is_fp32_grade(mt, case):
+    """The 5 x 5 stride-1 layers with 128-wide tiles run the 1-D Winograd F(2,5) transform (points 0, +-1, +-2, inf)
+    on split-fp16 operands: forward and backward-data against an fp64 convolution stay at fp32 rounding level
+    (the conditioning of the six-point transform in this arithmetic: scratch/r3_wino25_cond.py)."""
+    from master_thesis_amd import engine as E
+    n, h, w, cin, cout = case
+    tag = 'c5p.' + '.'.join(map(str, case))
+    x = S.uniform(tag + '.x', (n, cin, h, w), -1, 1)
+    wt = S.uniform(tag + '.w', (cout, cin, 5, 5), -0.1, 0.1)
+    bs = S.uniform(tag + '.b', (cout,), -0.5, 0.5)
+    gy = S.uniform(tag + '.gy', (n, cout, h, w), -1, 1)
+    x64 = x.double().requires_grad_(True)
+    y64 = F.conv2d(x64, wt.double(), bs.double(), padding=2)
+    y64.backward(gy.double())
+    y32 = F.conv2d(x, wt, bs, padding=2)
+    with E.precision('f16x3'):
+        xg = x.to(dev()).requires_grad_(True)
+        y4 = E.conv_stack(E.ToNHWC4Fn.apply(xg), [E.LayerSpec('c', cin, cout, 5, 1, 0)], [wt.to(dev()), bs.to(dev())])
+        y = E.FromNHWC4Fn.apply(y4, cout)
+        y.backward(gy.to(dev()))
+    e_fwd = float((y.detach().cpu().double() - y64.detach()).abs().max() / y64.detach().abs().max())
+    e_bwd = float((xg.grad.cpu().double() - x64.grad).abs().max() / x64.grad.abs().max())
+    e_ref = float((y32.double() - y64.detach()).abs().max() / y64.detach().abs().max())
+    print(f'5x5 {case}: fwd {e_fwd:.2e} bwd {e_bwd:.2e} (torch fp32 {e_ref:.2e})')
+    # measured: 1.5e-6 .. 2.9e-6 (the direct form: 3e-7 .. 1e-6; torch's own fp32 convolution: 4e-7 .. 5e-7)
+    assert e_fwd < 4e-6 and e_bwd < 4e-6, (e_fwd, e_bwd, e_ref)
 
 
 def test_tiny_exit_layer_gates_by_the_saved_activation(mt):
