@@ -448,6 +448,7 @@ def run_rank(args):
 
         def eager():
             opt.zero_grad()
+            mdist.arm_overlap(opt)            # N > 1: finished windows of the flat gradient go on the wire during the backward
             loss = model.training_step(batch, 0)
             loss.backward()
             mdist.sync_gradients(opt)

@@ -313,22 +313,6 @@ __device__ __forceinline__ void mfma_splitf(const bf16x8 (&a)[NS], const bf16x8 
   }
 }
 
-// the three partial products of a 2-term split on v_mfma_f32_16x16x32 (K = 32 per instruction)
-template <int FMT>
-__device__ __forceinline__ void mfma16_splitf(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x4& acc) {
-  if constexpr (FMT == 0) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
-  } else {
-    const half8 a0 = __builtin_bit_cast(half8, a[0]), a1 = __builtin_bit_cast(half8, a[1]);
-    const half8 b0 = __builtin_bit_cast(half8, b[0]), b1 = __builtin_bit_cast(half8, b[1]);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc, 0, 0, 0);
-  }
-}
-
 struct WgK {
   const float* d; long dsn, dsh, dsw; int Hd, Wd, Cd;
   const float* g; long gsn, gsh, gsw; int Hg, Wg, Cg;
@@ -383,11 +367,9 @@ inline int fill_convk(const mt_conv* d, ConvK* k) {
 // dst[tap 12 = ky*4 + xi][chunk][ntile][wn WN][kstep 2][plane 2][lane 64][8], lane (li, lh) holds
 // U[ky][xi][a = (ntile*WN + wn)*32 + li][b = chunk*32 + kstep*16 + 8*lh + j],  U = G g[ky][:]:
 // (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2) over the kernel row ky (taps flipped first when `flip`).
-// mf16 (128-wide tiles only): fragments of v_mfma_f32_16x16x32 instead -- the k-step slot becomes the 16-column
-// half nsub, lane (c, q) = (lane & 15, lane >> 4) holds U[..][a = .. + nsub*16 + c][b = chunk*32 + 8*q + j].
 __device__ __forceinline__ void pack_halo_wino_body(const float* src, int A, int B, long sa, long sb, long st, __bf16* dst,
                                                     int nchunk, int ntile, int flip, const float* wamax, int nchunk_total,
-                                                    int ch_off, int WN, int mf16 = 0) {
+                                                    int ch_off, int WN) {
   const float sc = wamax ? pow2_scale(*wamax) : 1.f;
   const long total = (long)12 * nchunk * ntile * WN * 2 * 64 * 8;      // elements per plane
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -398,8 +380,8 @@ __device__ __forceinline__ void pack_halo_wino_body(const float* src, int A, int
     const int ch = (int)(r % nchunk);
     const int t = (int)(r / nchunk);
     const int ky = t >> 2, xi = t & 3;
-    const int a = mf16 ? (nt * WN + wv) * 32 + ks * 16 + (lane & 15) : (nt * WN + wv) * 32 + (lane & 31);
-    const int b = mf16 ? ch * 32 + 8 * (lane >> 4) + j : ch * 32 + ks * 16 + 8 * (lane >> 5) + j;
+    const int a = (nt * WN + wv) * 32 + (lane & 31);
+    const int b = ch * 32 + ks * 16 + 8 * (lane >> 5) + j;
     float v = 0.f;
     if (a < A && b < B) {
       const float* g = src + a * sa + b * sb;

@@ -59,22 +59,32 @@ class RcclComm:
         L.call('mt_comm_unique_id', rccl_library_path().encode(), C.cast(buf, C.c_void_p))
         return bytes(buf.raw)
 
-    def allreduce_sum_(self, flat, bucket_floats=None):
-        """In-place SUM all-reduce of a 1-D fp32 CUDA tensor: the buckets run on the side stream
-        after everything already queued on the current stream; the current stream continues after
-        the last bucket.  Asynchronous with respect to the host."""
+    def enqueue_range_(self, flat, lo, hi, bucket_floats=None):
+        """SUM all-reduce of flat[lo:hi] in buckets on the side stream, after everything already queued on the
+        current stream.  Does NOT make the current stream wait: pair with join()."""
         assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
         bucket_floats = bucket_floats or BUCKET_FLOATS
         cur = torch.cuda.current_stream(self.device)
         self.ready.record(cur)
         self.stream.wait_event(self.ready)
-        n, base = flat.numel(), flat.data_ptr()
-        for off in range(0, n, bucket_floats):
-            k = min(bucket_floats, n - off)
+        base = flat.data_ptr()
+        for off in range(lo, hi, bucket_floats):
+            k = min(bucket_floats, hi - off)
             L.call('mt_allreduce_sum_f32', self.handle, C.c_void_p(base + 4 * off), k, C.c_void_p(self.stream.cuda_stream))
+
+    def join(self, flat):
+        """The current stream continues after the last bucket enqueued so far."""
+        cur = torch.cuda.current_stream(self.device)
         self.done.record(self.stream)
         cur.wait_event(self.done)
         flat.record_stream(self.stream)
+
+    def allreduce_sum_(self, flat, bucket_floats=None):
+        """In-place SUM all-reduce of a 1-D fp32 CUDA tensor: the buckets run on the side stream
+        after everything already queued on the current stream; the current stream continues after
+        the last bucket.  Asynchronous with respect to the host."""
+        self.enqueue_range_(flat, 0, flat.numel(), bucket_floats)
+        self.join(flat)
 
     def destroy(self):
         if self.handle:
@@ -170,22 +180,97 @@ def allreduce_flat_(flat, bucket_floats=None, async_op=False):
     return works
 
 
+# ---- the exchange overlapped with the backward --------------------------------------------------
+# The flat gradient buffer follows the parameter order, the backward finishes it from the back: each conv stack
+# (engine.ConvStackFn: FlowEstimator 256 / 64, the correlation mixer, SeparableConv4d -- 21 / 21 / 9 / 7 MB of the
+# DFPN's 55.7 MB) reports its parameters when its backward has enqueued their last weight-gradient reduce, and that
+# window of the buffer goes on the wire while the backward of the stacks in front of it still runs.  Eager steps
+# only (what a Lightning loop runs): inside a captured graph there is no hook point, the buckets follow the replay.
+# The loop arms ONE backward with arm_overlap(optimizer) and closes it with sync_gradients(optimizer), which sends
+# whatever was not reported and makes the stream wait for all of it.  MT355_DP_OVERLAP=0: everything at the end.
+OVERLAP = os.environ.get('MT355_DP_OVERLAP', '1') != '0'
+
+
+class _Pending:
+    flat = None        # the armed optimizer's flat gradient buffer
+    ranges = []        # [lo, hi) windows already on the wire
+    works = []         # torch.distributed work handles (fallback transport)
+
+
+_pend = _Pending()
+
+
+def arm_overlap(optimizer):
+    """The next backward may send finished windows of ``optimizer.flat_g`` early (no-op when not distributed)."""
+    if not (OVERLAP and is_dist()):
+        return
+    if _pend.flat is not None and _pend.ranges:
+        raise RuntimeError('arm_overlap: the previous backward was never closed with sync_gradients()')
+    _pend.flat, _pend.ranges, _pend.works = optimizer.flat_g, [], []
+
+
+def _send(flat, lo, hi):
+    for a, b in _pend.ranges:
+        if lo < b and a < hi:
+            raise RuntimeError(f'gradient window [{lo}, {hi}) was already exchanged in this backward (a module ran twice, or '
+                               'gradients are accumulated over several backward passes): set MT355_DP_OVERLAP=0')
+    comm = init_comm(flat.device) if flat.is_cuda else None
+    if comm is not None:
+        comm.enqueue_range_(flat, lo, hi)
+    else:
+        if flat.is_cuda and dist.get_backend() != 'nccl':
+            torch.cuda.current_stream().synchronize()        # gloo stages CUDA tensors through the host
+        for off in range(lo, hi, BUCKET_FLOATS):
+            _pend.works.append(dist.all_reduce(flat[off:min(hi, off + BUCKET_FLOATS)], op=dist.ReduceOp.SUM, async_op=True))
+    _pend.ranges.append((lo, hi))
+
+
+def grads_ready(params):
+    """engine hook: the backward has enqueued the last gradient launch of ``params`` (one conv stack)."""
+    flat = _pend.flat
+    if flat is None:
+        return
+    if flat.is_cuda and torch.cuda.is_current_stream_capturing():
+        return
+    gs = [p.grad for p in params if p is not None and p.requires_grad]
+    if not gs or any(not getattr(g, '_mt_flat', False) or g._base is not flat for g in gs):
+        return                                   # (gradients that autograd still has to accumulate: not final yet)
+    base = flat.data_ptr()
+    lo = min((g.data_ptr() - base) // 4 for g in gs)
+    hi = max((g.data_ptr() - base) // 4 + g.numel() for g in gs)
+    if sum(g.numel() for g in gs) == hi - lo:    # one contiguous window
+        _send(flat, lo, hi)
+
+
 def sync_gradients(optimizer):
-    """Average the gradients of a FlatAdam optimizer across ranks (sum here, 1/world in Adam)."""
+    """Average the gradients of a FlatAdam optimizer across ranks (sum here, 1/world in Adam): sends every
+    window of the flat buffer the armed backward has not sent already, then orders the stream behind all of it."""
     if not is_dist():
         optimizer.grad_scale = 1.0
         return
     flat = optimizer.flat_g
+    if _pend.flat is not flat:
+        _pend.flat, _pend.ranges, _pend.works = flat, [], []
+    pos = 0
+    for a, b in sorted(_pend.ranges) + [(flat.numel(), flat.numel())]:
+        if pos < a:
+            _send(flat, pos, a)
+        pos = max(pos, b)
     comm = init_comm(flat.device) if flat.is_cuda else None
     if comm is not None:
-        comm.allreduce_sum_(flat)                 # stream-ordered: no host synchronisation
-    else:
-        if flat.is_cuda and dist.get_backend() != 'nccl':
-            # gloo stages CUDA tensors through the host: drain the backward first so that the
-            # copy does not wait behind ~1.6 k queued launches through a cross-stream event
-            torch.cuda.current_stream().synchronize()
-        allreduce_flat_(flat)
+        comm.join(flat)                           # stream-ordered: no host synchronisation
+    for w in _pend.works:
+        w.wait()
+    _pend.flat, _pend.ranges, _pend.works = None, [], []
     optimizer.grad_scale = 1.0 / dist.get_world_size()
+
+
+def _install_hook():
+    from . import engine as E
+    E.GRADS_READY = grads_ready
+
+
+_install_hook()
 
 
 def broadcast_parameters(optimizer, src=0):

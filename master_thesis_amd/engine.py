@@ -16,6 +16,7 @@ from . import _lib as L
 WEIGHT_EPOCH = 0          # bumped by the optimizer: packed-weight cache key
 _pack_cache = {}
 PROFILE = None            # list -> every conv-engine launch appends (kernel, flops, ev0, ev1)
+GRADS_READY = None        # callable(params): a conv stack's backward has enqueued its last gradient launch (dist.py)
 # MFMA arithmetic of the conv engine (include/mt355.h, mt_precision):
 #   'f16x3'   2-term fp16 split of power-of-two scaled tensors, 3 partial products:
 #             ~7e-8 relative per product (fp32-grade).  Halo-tile kernels only;
@@ -98,7 +99,6 @@ WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '512'))
 # (DFPN / CHN) with either setting, the fp32 CPU oracle itself 5.2e-5 / 8.7e-5; four optimizer steps track the
 # three-product run to 3e-7 in the loss.  Forward and backward-DATA products always keep both terms of both operands.
 WGRAD_D_TERMS = int(os.environ.get('MT355_WGRAD_D_TERMS', '1'))
-HALO_RB32 = os.environ.get('MT355_HALO_RB32', '0') == '1'  # mirrors halo_rb32_wanted() in conv_halo.hip (off by default)
 HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_enabled() in conv_halo_wino.hip
 HALO_WINO25 = os.environ.get('MT355_WINO25', '1') != '0'  # mirrors halo_wino25_enabled() in conv_halo_wino25.hip
 TINY_OUT = os.environ.get('MT355_TINY_OUT', '1') != '0'   # ... and for 128 -> 1 / 2 channel layers (A/B switch)
@@ -120,8 +120,6 @@ def tiny_in_eligible(kind_c, stride, k, pad, ups, cin_real, cout_real, x_cp):
 def _igemm_name(co, halo, prec, cin_p=0):
     """Name of the kernel mt_conv_run picks (profiling labels only)."""
     cfg = '2,2,2,2' if co > 64 else ('2,2,2,1' if co > 32 else '4,1,1,1')
-    if halo and prec in ('f16x3', 'bf16x3') and cin_p > 32 and co <= 32 and HALO_RB32:
-        return 'igemm_halo_rb32_kernel<%s>|{k}' % ('f16' if prec == 'f16x3' else 'bf16')
     if halo and prec in ('f16x3', 'bf16x3') and cin_p > 32 and co > 32 and HALO_RB:
         # ('{k}' == 3: the 1-D Winograd F(2,3) variant; the caller substitutes k)
         return 'igemm_halo_{rbw}_kernel<{k},%s,%d>' % ('f16' if prec == 'f16x3' else 'bf16', 1 if co > 64 else 2)
@@ -137,10 +135,6 @@ def _kname(template, k, co=0, ho=0, cin_p=0):
     32-channel chunks, the 5 x 5 ones (igemm_wino25_kernel)."""
     if k == 5 and HALO_WINO25 and '{rbw}' in template and co > 64 and cin_p > 32 and cin_p % 32 == 0:
         return 'igemm_wino25_kernel<%s>' % ('f16' if ',f16' in template else 'bf16')
-    if '|{k}' in template:            # the 32-output-channel register-B kernel exists for 3 x 3 only
-        if k == 3:
-            return template.split('|')[0]
-        return 'igemm_halo_kernel<%d,%s,4,1,1,1>' % (k, '2,f16' if 'f16>' in template and 'bf16' not in template else '2,bf16')
     if k == 3 and HALO_WINO and '{rbw}' in template:
         fmt = 'f16' if ',f16' in template else 'bf16'
         if co > 64 and ho > 8:
@@ -819,7 +813,9 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
                       and os.environ.get('MT355_WGRAD3_TALL', '1') != '0') else 4
         ntiles = dv.N * ((dv.H + trows - 1) // trows) * ((dv.W + 15) // 16)
         want = WGRAD_PC_BLOCKS if pc else 512        # blocks in flight: one 512-thread block per CU for pc
-        d.d_terms = WGRAD_D_TERMS if (pc or spec.stride == 2) else 0      # (the stride-2 gathers of the single-role kernel too)
+        # (fp16 terms only: the leading bf16 term has 8 bits -- 1.3e-3 on a noise gradient; the stride-2 gathers of the
+        # single-role kernel take the option too)
+        d.d_terms = WGRAD_D_TERMS if ((pc or spec.stride == 2) and prec == 'f16x3') else 0
         d.splits = max(1, min((want + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 256))
     else:
         d.splits = _splits(tiles * t, pixels)
@@ -987,6 +983,8 @@ class ConvStackFn(torch.autograd.Function):
                                dx_window=sp.dx_window if i == 0 else None)
             dz = dx
             acts[i + 1] = None   # release the saved activation
+        if GRADS_READY is not None:
+            GRADS_READY(params)
         return (dz, None, None) + tuple(grads)
 
 

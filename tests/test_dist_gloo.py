@@ -80,6 +80,33 @@ def _worker_flat_adam(rank, world, port, out):
     dist.all_gather(both, local)
     ok = ok and torch.allclose(opt.flat_g * opt.grad_scale, (both[0] + both[1]) / 2) and opt.grad_scale == 0.5
     ok = ok and mdist.transport() == 'torch.distributed/gloo'
+    # the exchange overlapped with the backward: windows of the flat buffer reported by the engine's hook go on
+    # the wire early (here: the last parameter, as a backward would finish it first), sync_gradients sends the rest
+    from master_thesis_amd import engine as E
+    ok = ok and E.GRADS_READY is mdist.grads_ready
+    for early in ([[2]], [[2], [0, 1]], []):
+        for p in params:
+            p.grad.copy_(torch.rand(p.shape, generator=g))
+        local = opt.flat_g.clone()
+        mdist.arm_overlap(opt)
+        for group in early:
+            E.GRADS_READY([params[i] for i in group])
+        ok = ok and len(mdist._pend.ranges) == len(early)
+        mdist.sync_gradients(opt)
+        dist.all_gather(both, local)
+        ok = ok and torch.allclose(opt.flat_g, both[0] + both[1]) and mdist._pend.flat is None
+    # a window reported twice in one backward is an error, not a silent double reduction
+    mdist.arm_overlap(opt)
+    E.GRADS_READY([params[2]])
+    try:
+        E.GRADS_READY([params[2]])
+        ok = False
+    except RuntimeError:
+        pass
+    mdist.sync_gradients(opt)
+    # ... and without arm_overlap the hook does nothing
+    E.GRADS_READY([params[2]])
+    ok = ok and mdist._pend.flat is None and not mdist._pend.ranges
     out[rank] = bool(ok)
     dist.destroy_process_group()
 

@@ -52,7 +52,14 @@ def _rank(rank, world, port, backend, out):
     opt.zero_grad()
     loss = model.training_step(batch, 0)
     loss.backward()
-    local = opt.flat_g.clone()
+    local = opt.flat_g.clone()                      # this rank's own gradient (nothing exchanged: not armed)
+    # the same step again with the exchange overlapped with the backward: the four conv stacks of the DFPN report
+    # their windows of the flat buffer as the backward finishes them (dist.grads_ready), sync_gradients sends the rest
+    opt.zero_grad()
+    mdist.arm_overlap(opt)
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    early = len(mdist._pend.ranges)
     mdist.sync_gradients(opt)                       # the real exchange (RCCL through the C ABI on nccl)
     flat = (opt.flat_g * opt.grad_scale).clone()
     both = [torch.empty_like(local) for _ in range(world)]
@@ -63,7 +70,7 @@ def _rank(rank, world, port, backend, out):
     ps = [torch.empty_like(opt.flat_p) for _ in range(world)]
     dist.all_gather(ps, opt.flat_p)
     same = all(torch.equal(ps[0], p) for p in ps[1:])
-    out[rank] = (err, bool(same), float(local.norm()), mdist.transport())
+    out[rank] = (err, bool(same), float(local.norm()), mdist.transport(), early)
     mdist.shutdown()
     dist.destroy_process_group()
 
@@ -74,8 +81,9 @@ def _run(world, backend):
     mp.spawn(_rank, args=(world, _free_port(), backend, out), nprocs=world, join=True)
     res = dict(out)
     assert len(res) == world
-    for r, (err, same, norm, transport) in res.items():
-        assert norm > 0 and err < 1e-6 and same, (r, err, same, norm)
+    for r, (err, same, norm, transport, early) in res.items():
+        # (two backward passes of the same step differ by the rounding of a few float atomics)
+        assert norm > 0 and err < 1e-5 and same and early == 4, (r, err, same, norm, early)
     return res
 
 
