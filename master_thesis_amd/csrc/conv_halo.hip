@@ -366,6 +366,7 @@ __host__ __device__ inline int halo_ck(int cin_p, int ns) { return (ns == 3 || (
 
 }  // namespace
 bool halo_wino_enabled();                                            // conv_halo_wino.hip
+bool halo_winox_wanted(int cin_p, int cout_p, int T);
 void mt_halo_wino_launch(const void* convk, int fmt, void* stream);
 bool halo_wino25_wanted(int cin_p, int cout_p, int T);               // conv_halo_wino25.hip
 void mt_halo_wino25_launch(const void* convk, int fmt, void* stream);
@@ -373,7 +374,9 @@ void mt_pack_halo_wino25_launch(const float* src, int A, int B, long sa, long sb
                                 int flip, const float* wamax, int nchunk_total, int ch_off, void* stream);
 namespace {
 // 1-D Winograd F(2,3) on the 3 x 3 layers the register-B kernel would take (T = 9 taps)
-bool halo_wino_wanted(int cin_p, int cout_p, int T) { return T == 9 && halo_rb_wanted(cin_p, cout_p) && halo_wino_enabled(); }
+bool halo_wino_wanted(int cin_p, int cout_p, int T) {
+  return T == 9 && ((halo_rb_wanted(cin_p, cout_p) && halo_wino_enabled()) || halo_winox_wanted(cin_p, cout_p, T));
+}
 
 template <int KS, int NS, int FMT>
 void launch_halo(const ConvK& k, hipStream_t s) {
@@ -631,9 +634,9 @@ extern "C" int mt_weight_pack_halo_part(const float* src, int32_t A, int32_t B, 
 extern "C" int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, int32_t T, int32_t precision) {
   if (precision == MT_PREC_BF16X6) return 0;
   if (halo_wino25_wanted(BP_total, AP, T)) return 5;        // 5: F(2,5) fragments (igemm_wino25_kernel)
+  if (halo_wino_wanted(BP_total, AP, T)) return 2;          // 2: Winograd F(2,3) fragments
   if (!halo_rb_wanted(BP_total, AP)) return 0;
-  if (!halo_wino_wanted(BP_total, AP, T)) return 1;
-  return 2;                                            // 2: Winograd F(2,3) fragments
+  return 1;
 }
 
 extern "C" int mt_absmax_segments(const mt_amax_seg* segs_dev, int32_t nseg, void* stream) {

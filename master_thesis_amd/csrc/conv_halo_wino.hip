@@ -190,6 +190,191 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_wino_kernel(ConvK p, int ti
   if (p.yamax) raise_amax(p.yamax, vmax);
 }
 
+// ---- <= 64 output channels: the XI axis split over the waves (round 3) ------------------------
+// The dense blocks of the RRDB trunk (model_chn.py:588-623) are 3 x 3 layers with 64 .. 192 gathered and only 32 or
+// 64 output channels, at 64 x 64 pixels: ~45 us launches of one wave of blocks.  With a 32-wide n-tile the four waves
+// of a block cannot split the channels, and splitting the pixels (igemm_halo_kernel<.., 4, 1, 1, 1>, igemm_halo_wino_
+// kernel<., 2>) leaves a wave ONE 32 x 32 tile per fragment pair: every A and every B fragment is fetched for a single
+// MFMA triple, with a barrier per tap.  Here the waves split the four xi of the Winograd transform instead: wave w
+// owns xi = w for ALL 64 (row, pair) GEMM rows of the 8 x 16 tile and all TN 32-channel tiles -- each A fragment pair
+// feeds TN triples, each B pair two, 12 TN MFMAs per (kernel row, xi) tap, 16 TN accumulator registers -- and walks
+// only its 3 of the 12 taps; weight fragments come straight from global memory (every wave reads different ones:
+// nothing is fetched twice by a block), the image is single-buffered (41 KB: three blocks per CU), two barriers per
+// 32-channel chunk.  The four xi meet in the epilogue through LDS: per M tile every wave posts its products, then
+// finishes one output row of the tile (y0 = m0 + m1 + m2, y1 = m1 - m2 - m3).
+template <int FMT, int TN>
+__global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK p, int tiles_y, int tiles_x) {
+  constexpr int NS = 2, CK = 32, TH = 8, TW = 16, BN = 32 * TN, TM = 2;
+  constexpr int NTX = TW / 2, ROWS = TH + 2;
+  constexpr int ENT = CK, ROW_E = 4 * NTX * ENT + 8, PLANE_E = ROWS * ROW_E;
+  constexpr int NIT = ROWS * NTX * (CK / 4), RI = (NIT + 255) / 256;
+  constexpr int KSTEPS = CK / 16;
+  static_assert(4 * TN * 16 * 64 * 4 <= NS * PLANE_E * 2, "the epilogue exchange of one M tile must fit the image");
+  __shared__ __attribute__((aligned(16))) __bf16 sV[NS * PLANE_E];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx_ = bid % tiles_x; bid /= tiles_x;
+  const int ty_ = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int ty0 = ty_ * TH, tx0 = tx_ * TW, n0 = blockIdx.y * BN;
+  const int HL = p.H << p.ups, WL = p.W << p.ups;
+  const float scA = FMT ? pow2_scale(*p.xamax) : 1.f;
+  const float inv = FMT ? 1.f / (scA * pow2_scale(*p.wamax)) : 1.f;
+  const float* xin = p.x + (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
+
+  // ---- transform items: (halo row r, column pair t, channel quad c4), c4 fastest (as igemm_halo_wino_kernel)
+  int it_row[RI], it_lx[RI];
+  unsigned it_ok[RI];
+#pragma unroll
+  for (int i = 0; i < RI; ++i) {
+    const int q = tid + 256 * i;
+    const int c4 = q & 7, t = (q >> 3) & 7, r = q >> 6;
+    const int ly = ty0 - 1 + r;
+    it_ok[i] = 0;
+    it_lx[i] = tx0 - 1 + 2 * t;
+    it_row[i] = (int)((long)(ly >> p.ups) * p.xsh) + 4 * c4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int lx = it_lx[i] + b;
+      const bool ok = q < NIT && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL;
+      it_ok[i] |= ok ? (1u << b) : 0u;
+    }
+  }
+  const int xsw = (int)p.xsw;
+  f32x4 rh[RI][4];
+  auto load_raw = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      const int c4 = (tid + 256 * i) & 7;
+      const bool cin = c0 + 4 * c4 < p.C;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (((it_ok[i] >> b) & 1u) && cin)
+          v = *reinterpret_cast<const f32x4*>(xin + (it_row[i] + ((it_lx[i] + b) >> p.ups) * xsw + c0));
+        rh[i][b] = v;
+      }
+    }
+  };
+  auto store_v = [&]() {
+#pragma unroll
+    for (int i = 0; i < RI; ++i) {
+      const int q = tid + 256 * i;
+      if (q < NIT) {
+        const int c4 = q & 7, t = (q >> 3) & 7, r = q >> 6;
+        const f32x4 d0 = rh[i][0], d1 = rh[i][1], d2 = rh[i][2], d3 = rh[i][3];
+        const f32x4 v[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+        __bf16* dst = sV + r * ROW_E + t * ENT + 4 * c4;
+#pragma unroll
+        for (int x4 = 0; x4 < 4; ++x4) {
+          bf16x4 parts[NS];
+          split4f<NS, FMT>(v[x4], scA, parts);
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+            *reinterpret_cast<bf16x4*>(dst + s * PLANE_E + x4 * NTX * ENT) = parts[s];
+        }
+      }
+    }
+  };
+  // weight fragments: [tap 12 = ky * 4 + xi][chunk][ntile][wn TN][kstep][plane][lane] x 16 B (mt_weight_pack_halo, order 2)
+  const bf16x8* wfr = reinterpret_cast<const bf16x8*>(p.wt);
+  const int nchunk = (p.C + CK - 1) / CK, ntile_w = (p.Co + BN - 1) / BN;
+  bf16x8 fb[TN][KSTEPS][NS];
+  auto load_B = [&](int ch, int ky, int tn, int ks) {
+    const bf16x8* f = wfr + ((((long)(ky * 4 + xi) * nchunk + ch) * ntile_w + blockIdx.y) * TN + tn) * (KSTEPS * NS * 64) +
+                      ks * NS * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) fb[tn][ks][s] = f[s * 64];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][tn][r] = 0.f;
+
+  // MFMA row i of M tile a = (output row 4a + (i >> 3), column pair i & 7); this wave's xi plane of the image
+  int a_base[TM];
+#pragma unroll
+  for (int a = 0; a < TM; ++a) a_base[a] = (4 * a + (li >> 3)) * ROW_E + (li & 7) * ENT + 8 * lh + xi * NTX * ENT;
+
+  load_raw(0);
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) load_B(0, 0, tn, ks);
+  store_v();
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const bool more = ch + 1 < nchunk;
+    if (more) load_raw((ch + 1) * CK);          // in flight under the three taps
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int toff = ky * ROW_E;
+      bf16x8 fa[KSTEPS][TM][NS];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+            fa[ks][a][s] = *reinterpret_cast<const bf16x8*>(&sV[s * PLANE_E + a_base[a] + toff + ks * 16]);
+      __builtin_amdgcn_sched_barrier(0);     // (all fragment reads of the tap are requested ahead of its MFMAs)
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+          for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(fa[ks][a], fb[tn][ks], acc[a][tn]);
+          if (ky < 2) load_B(ch, ky + 1, tn, ks);
+          else if (more) load_B(ch + 1, 0, tn, ks);
+        }
+      }
+    }
+    if (more) {
+      __syncthreads();            // every wave is done reading this chunk's image
+      store_v();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: the four xi meet through LDS, one M tile at a time; wave w finishes output row 4a + w ---------
+  float* xch = reinterpret_cast<float*>(sV);       // [xi 4][tn][16][64 lanes]
+  float vmax = 0.f;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    __syncthreads();                               // the image (a == 0) / the previous tile's products are dead
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[((xi * TN + tn) * 16 + r) * 64 + lane] = acc[a][tn][r];
+    __syncthreads();
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      float vals[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 4 * xi + q;                  // C/D rows (r & 3) + 8 (r >> 2) + 4 lh: output row r >> 2 = xi of the M tile
+        const float m0 = xch[((0 * TN + tn) * 16 + r) * 64 + lane], m1 = xch[((1 * TN + tn) * 16 + r) * 64 + lane];
+        const float m2 = xch[((2 * TN + tn) * 16 + r) * 64 + lane], m3 = xch[((3 * TN + tn) * 16 + r) * 64 + lane];
+        vals[2 * q] = (m0 + m1 + m2) * inv;
+        vals[2 * q + 1] = (m1 - m2 - m3) * inv;
+      }
+      const int oy_ = ty0 + 4 * a + xi, oxb = tx0 + 8 * lh;
+      vmax = fmaxf(vmax, halo_epilogue_lean<8>(p, n, n0 + tn * 32 + li, vals, [&](int e, int& oy, int& ox) {
+        oy = oy_;
+        ox = oxb + 2 * (e >> 1) + (e & 1);       // column pair (r & 3) + 4 lh
+      }));
+    }
+  }
+  if (p.yamax) raise_amax(p.yamax, vmax);
+}
+
 // ---- 16 x 16-pixel tiles, 8 waves, double-buffered image ------------------------------------
 // The 8 x 16 kernel above leaves a wave 12 MFMAs per tap (four accumulator sets cost it half of the
 // direct kernel's pixel tile), which is too little to cover the latency of its weight fragments
@@ -384,12 +569,33 @@ bool halo_wino_enabled() {
   return on;
 }
 
-// Launch for a layer launch_halo<3, 2, FMT> sends to the register-B path (C > 32, Co > 32).
+// MT355_WINOX=0: layers with <= 64 output channels stay on the pixel-split kernels (A/B switch, read once).
+bool halo_winox_enabled() {
+  static const bool on = [] { const char* e = getenv("MT355_WINOX"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+// 3 x 3 layers of the xi-split kernel: more than one 32-channel K chunk's worth of gathered channels, <= 64 outputs
+bool halo_winox_wanted(int cin_p, int cout_p, int T) {
+  return T == 9 && halo_wino_enabled() && halo_winox_enabled() && cin_p > 32 && cout_p <= 64;
+}
+
+// Launch for a layer launch_halo<3, 2, FMT> sends to the Winograd path (C > 32; Co > 32, or any Co with the xi-split kernel).
 void mt_halo_wino_launch(const void* kp, int fmt, void* stream) {
   const ConvK& k = *static_cast<const ConvK*>(kp);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_y = (k.Ho + 7) / 8, tiles_x = (k.Wo + 15) / 16;
   const unsigned nt = (unsigned)k.N * tiles_y * tiles_x;
+  if (halo_winox_wanted(k.C, k.Co, 9)) {
+    if (k.Co > 32) {
+      if (fmt) hipLaunchKernelGGL((igemm_winox_kernel<1, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+      else hipLaunchKernelGGL((igemm_winox_kernel<0, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+    } else {
+      if (fmt) hipLaunchKernelGGL((igemm_winox_kernel<1, 1>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+      else hipLaunchKernelGGL((igemm_winox_kernel<0, 1>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+    }
+    return;
+  }
   static const bool big = [] { const char* e = getenv("MT355_WINO16"); return !(e && e[0] == '0'); }();
   if (k.Co > 64 && big && k.Ho > 8) {          // 16 x 16 tiles (an 8-row image would waste half of one)
     const int ty16 = (k.Ho + 15) / 16;
