@@ -368,7 +368,7 @@ __host__ __device__ inline int halo_ck(int cin_p, int ns) { return (ns == 3 || (
 bool halo_wino_enabled();                                            // conv_halo_wino.hip
 bool halo_winox_wanted(int cin_p, int cout_p, int T);
 void mt_halo_wino_launch(const void* convk, int fmt, void* stream);
-bool halo_wino25_wanted(int cin_p, int cout_p, int T);               // conv_halo_wino25.hip
+bool halo_wino25_wanted(int cin_p, int cout_p, int T, int f16);      // conv_halo_wino25.hip
 void mt_halo_wino25_launch(const void* convk, int fmt, void* stream);
 void mt_pack_halo_wino25_launch(const float* src, int A, int B, long sa, long sb, long st, void* dst, int nchunk, int ntile,
                                 int flip, const float* wamax, int nchunk_total, int ch_off, void* stream);
@@ -387,7 +387,7 @@ void launch_halo(const ConvK& k, hipStream_t s) {
       mt_halo_wino_launch(&k, FMT, s);
       return;
     }
-    if (KS == 5 && k.ups == 0 && halo_wino25_wanted(k.C, k.Co, 25)) {      // 1-D Winograd F(2,5), 128-wide tiles
+    if (KS == 5 && k.ups == 0 && halo_wino25_wanted(k.C, k.Co, 25, FMT)) {      // 1-D Winograd F(2,5), 128-wide tiles
       mt_halo_wino25_launch(&k, FMT, s);
       return;
     }
@@ -575,7 +575,7 @@ extern "C" int64_t mt_weight_pack_halo_elems(int32_t AP, int32_t BP, int32_t T, 
   const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = halo_ck(BP, NS), LD = CK + 8;
   const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);
   if (NS == 2 && halo_wino_wanted(BP, AP, T)) T = 12;      // the (ky, xi) "taps" of the Winograd image (fragment order)
-  else if (NS == 2 && halo_wino25_wanted(BP, AP, T)) T = 30;   // F(2,5): 5 kernel rows x 6 xi
+  else if (NS == 2 && halo_wino25_wanted(BP, AP, T, precision == MT_PREC_F16X3)) T = 30;   // F(2,5): 5 kernel rows x 6 xi
   return (int64_t)T * ((BP + CK - 1) / CK) * ((AP + BN - 1) / BN) * NS * BN * LD;
 }
 
@@ -600,7 +600,7 @@ static int pack_halo_impl(const float* src, int32_t A, int32_t B, int32_t T, int
                        reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, w_amax, nchunk_total, ch_off, BN / 32);
     return mt_check_launch("mt_weight_pack_halo(wino)");
   }
-  if (NS == 2 && halo_wino25_wanted(BP_total, AP, T)) {   // F(2,5)-transformed fragments for igemm_wino25_kernel
+  if (NS == 2 && halo_wino25_wanted(BP_total, AP, T, precision == MT_PREC_F16X3)) {   // F(2,5)-transformed fragments for igemm_wino25_kernel
     mt_pack_halo_wino25_launch(src, A, B, (long)sa, (long)sb, (long)st, dst, nchunk, ntile, flip, w_amax, nchunk_total, ch_off, stream);
     return mt_check_launch("mt_weight_pack_halo(wino25)");
   }
@@ -633,7 +633,7 @@ extern "C" int mt_weight_pack_halo_part(const float* src, int32_t A, int32_t B, 
 
 extern "C" int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, int32_t T, int32_t precision) {
   if (precision == MT_PREC_BF16X6) return 0;
-  if (halo_wino25_wanted(BP_total, AP, T)) return 5;        // 5: F(2,5) fragments (igemm_wino25_kernel)
+  if (halo_wino25_wanted(BP_total, AP, T, precision == MT_PREC_F16X3)) return 5;        // 5: F(2,5) fragments (igemm_wino25_kernel)
   if (halo_wino_wanted(BP_total, AP, T)) return 2;          // 2: Winograd F(2,3) fragments
   if (!halo_rb_wanted(BP_total, AP)) return 0;
   return 1;

@@ -366,10 +366,13 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK
         vals[2 * q + 1] = (m1 - m2 - m3) * inv;
       }
       const int oy_ = ty0 + 4 * a + xi, oxb = tx0 + 8 * lh;
-      vmax = fmaxf(vmax, halo_epilogue_lean<8>(p, n, n0 + tn * 32 + li, vals, [&](int e, int& oy, int& ox) {
+      auto pix = [&](int e, int& oy, int& ox) {
         oy = oy_;
         ox = oxb + 2 * (e >> 1) + (e & 1);       // column pair (r & 3) + 4 lh
-      }));
+      };
+      // (the 32-wide variant lives on occupancy: the sequential form; the 64-wide one batches the optional operands' loads)
+      if constexpr (TN == 1) vmax = fmaxf(vmax, halo_epilogue_lean<8>(p, n, n0 + tn * 32 + li, vals, pix));
+      else vmax = fmaxf(vmax, halo_epilogue<8>(p, n, n0 + tn * 32 + li, vals, pix));
     }
   }
   if (p.yamax) raise_amax(p.yamax, vmax);
@@ -577,7 +580,8 @@ bool halo_winox_enabled() {
 
 // 3 x 3 layers of the xi-split kernel: more than one 32-channel K chunk's worth of gathered channels, <= 64 outputs
 bool halo_winox_wanted(int cin_p, int cout_p, int T) {
-  return T == 9 && halo_wino_enabled() && halo_winox_enabled() && cin_p > 32 && cout_p <= 64;
+  static const int c64 = [] { const char* e = getenv("MT355_WINOX64"); return e ? atoi(e) : 128; }();   // (lab: min. gathered channels for 64-wide)
+  return T == 9 && halo_wino_enabled() && halo_winox_enabled() && cin_p > 32 && (cout_p <= 32 || (cout_p <= 64 && cin_p >= c64));
 }
 
 // Launch for a layer launch_halo<3, 2, FMT> sends to the Winograd path (C > 32; Co > 32, or any Co with the xi-split kernel).

@@ -263,8 +263,10 @@ bool halo_wino25_enabled() {
 
 // 5 x 5 layers this kernel takes: 128-wide output-channel tiles, whole 32-channel K chunks on the gathered side,
 // no up-sampled gather (mt_halo_try_launch has already established stride 1, "same" padding, a two-term split)
-bool halo_wino25_wanted(int cin_p, int cout_p, int T) {
-  return T == 25 && halo_wino25_enabled() && cin_p > 32 && (cin_p & 31) == 0 && cout_p > 64;
+// fp16 split only: with the 16 significant bits of a two-term bf16 split the six-point transform is off by 5e-3 on a
+// 128-channel layer (the direct form: 1e-5), so MT_PREC_BF16X3 keeps the direct kernel.
+bool halo_wino25_wanted(int cin_p, int cout_p, int T, int f16) {
+  return T == 25 && f16 && halo_wino25_enabled() && cin_p > 32 && (cin_p & 31) == 0 && cout_p > 64;
 }
 
 void mt_halo_wino25_launch(const void* kp, int fmt, void* stream) {
@@ -273,8 +275,8 @@ void mt_halo_wino25_launch(const void* kp, int fmt, void* stream) {
   const int tiles_y = (k.Ho + 7) / 8, tiles_x = (k.Wo + 15) / 16;
   const unsigned nt = (unsigned)k.N * tiles_y * tiles_x, ntn = (k.Co + 127) / 128;
   const unsigned grid = 8 * ((nt + 7) / 8) * ntn;       // (padded so that every XCD gets the same number of block slots)
-  if (fmt) hipLaunchKernelGGL((igemm_wino25_kernel<1>), dim3(grid), dim3(512), 0, s, k, tiles_y, tiles_x);
-  else hipLaunchKernelGGL((igemm_wino25_kernel<0>), dim3(grid), dim3(512), 0, s, k, tiles_y, tiles_x);
+  (void)fmt;                                            // (halo_wino25_wanted admits the fp16 split only)
+  hipLaunchKernelGGL((igemm_wino25_kernel<1>), dim3(grid), dim3(512), 0, s, k, tiles_y, tiles_x);
 }
 
 void mt_pack_halo_wino25_launch(const float* src, int A, int B, long sa, long sb, long st, void* dst, int nchunk, int ntile,

@@ -102,6 +102,7 @@ WGRAD_D_TERMS = int(os.environ.get('MT355_WGRAD_D_TERMS', '1'))
 HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_enabled() in conv_halo_wino.hip
 HALO_WINO25 = os.environ.get('MT355_WINO25', '1') != '0'  # mirrors halo_wino25_enabled() in conv_halo_wino25.hip
 HALO_WINOX = os.environ.get('MT355_WINOX', '1') != '0'    # mirrors halo_winox_enabled() in conv_halo_wino.hip
+WINOX64 = int(os.environ.get('MT355_WINOX64', '128'))     # ... and its threshold for 64-wide layers (lab)
 TINY_OUT = os.environ.get('MT355_TINY_OUT', '1') != '0'   # ... and for 128 -> 1 / 2 channel layers (A/B switch)
 TINY = os.environ.get('MT355_TINY', '1') != '0'           # fp32 VALU kernels for layers with <= 4 channels on one side (conv_tiny.hip)
 
@@ -134,10 +135,11 @@ def _kname(template, k, co=0, ho=0, cin_p=0, ups=0):
     """Profiling label of a register-B shape: the Winograd kernels take the 3 x 3 layers
     (igemm_wino16_kernel: Cout > 64 and more than 8 output rows) and, with 128-wide tiles and whole
     32-channel chunks, the 5 x 5 ones (igemm_wino25_kernel)."""
-    if k == 5 and HALO_WINO25 and '{rbw}' in template and co > 64 and cin_p > 32 and cin_p % 32 == 0 and ups == 0:
-        return 'igemm_wino25_kernel<%s>' % ('f16' if ',f16' in template else 'bf16')
-    if (k == 3 and HALO_WINO and HALO_WINOX and 'igemm_halo' in template and cin_p > 32 and 0 < co <= 64
-            and '3,bf16' not in template):          # the xi-split Winograd kernel (two-term splits, <= 64 output channels)
+    if (k == 5 and HALO_WINO25 and '{rbw}' in template and ',f16' in template and co > 64 and cin_p > 32 and cin_p % 32 == 0
+            and ups == 0):
+        return 'igemm_wino25_kernel<f16>'
+    if (k == 3 and HALO_WINO and HALO_WINOX and 'igemm_halo' in template and cin_p > 32 and '3,bf16' not in template
+            and (0 < co <= 32 or (co <= 64 and cin_p >= WINOX64))):          # the xi-split Winograd kernel (two-term splits, <= 64 output channels)
         return 'igemm_winox_kernel<%s,%d>' % ('f16' if 'f16' in template.replace('bf16', '') else 'bf16', 2 if co > 32 else 1)
     if k == 3 and HALO_WINO and '{rbw}' in template:
         fmt = 'f16' if ',f16' in template else 'bf16'

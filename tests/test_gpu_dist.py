@@ -82,8 +82,10 @@ def _run(world, backend):
     res = dict(out)
     assert len(res) == world
     for r, (err, same, norm, transport, early) in res.items():
-        # (two backward passes of the same step differ by the rounding of a few float atomics)
-        assert norm > 0 and err < 1e-5 and same and early == 4, (r, err, same, norm, early)
+        # (two backward passes of the same step differ by up to ~1e-4 of the largest gradient entry: a few kernels
+        # accumulate with float atomics -- measured 9e-6 .. 1.1e-4, scratch/r3_overlap_diag.py; a window that was
+        # dropped or reduced twice would be off by O(1))
+        assert norm > 0 and err < 1e-3 and same and early == 4, (r, err, same, norm, early)
     return res
 
 
