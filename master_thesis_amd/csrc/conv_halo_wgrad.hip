@@ -97,11 +97,13 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
       rg[i] = v;
     }
   };
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};      // DT < NS: the bias sums come from the fp32 values (see wgrad_pc_kernel)
   auto store_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < RD; ++i) {
       bf16x4 parts[NS];
       split4f<NS, FMT>(rd[i], scD, parts);
+      if constexpr (DT != NS) bsum += rd[i];
       const int px = (tid + 256 * i) / (CH / 4);
 #pragma unroll
       for (int s = 0; s < DT; ++s) *reinterpret_cast<bf16x4*>(&sD[s][px * LD + c4]) = parts[s];
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
       bf16x8 fa[NS];
 #pragma unroll
       for (int s = 0; s < DT; ++s) fa[s] = tr_frag(sD[s], a_off + ks * 16 * LD, LD);
-      if (do_bias) {
+      if (do_bias && DT == NS) {
 #pragma unroll
         for (int s = DT - 1; s >= 0; --s) {
           if constexpr (FMT == 0) acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], ones, acc_bias, 0, 0, 0);
@@ -181,7 +183,24 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
   const int T = p.KH * p.KW, li = lane & 31;
   const int TS = T + (with_bias ? 1 : 0);        // the bias sums travel as one more "tap" (column 0)
   float* slab = p.slabs + (long)split * p.Cd * TS * p.Cg;
-  if (do_bias && wn == 0 && li == 0) {
+  if constexpr (DT != NS) {
+    // thread (pixel column tid >> 4, channels 4 (tid & 15) ..): shuffles over the lane groups, LDS over the four waves
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bsum[j] += __shfl_xor(bsum[j], 16, 64); bsum[j] += __shfl_xor(bsum[j], 32, 64); }
+    __syncthreads();                             // every wave is done with the last tile's images
+    float* bl = reinterpret_cast<float*>(&sD[0][0]);
+    if (lane < 16) *reinterpret_cast<f32x4*>(&bl[wave * 64 + lane * 4]) = bsum;
+    __syncthreads();
+    if (do_bias && wave == 0 && lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ai = a0 + lane * 4 + j;
+        const float v = (bl[lane * 4 + j] + bl[64 + lane * 4 + j]) + (bl[128 + lane * 4 + j] + bl[192 + lane * 4 + j]);
+        if (ai < p.Cd) slab[((long)ai * TS + T) * p.Cg] = v;
+      }
+    }
+  }
+  if (do_bias && DT == NS && wn == 0 && li == 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -254,11 +273,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
   const int t_beg = split * tiles_per_split, t_end = min(ntiles, t_beg + tiles_per_split);
   const int HL = p.Hg << p.ups, WL = p.Wg << p.ups;
   const float scD = FMT ? pow2_scale(*pdamax) : 1.f, scG = FMT ? pow2_scale(*pgamax) : 1.f;
-  const float inv = 1.f / (scD * scG), inv_d = 1.f / scD;
+  const float inv = 1.f / (scD * scG);
 
+  // The bias gradient (sum of D over the pixels, the slabs' extra "tap") is accumulated by the STAGING waves from
+  // the fp32 values they load anyway -- every D pixel passes through exactly one of their registers -- in plain fp32:
+  // no MFMAs for it on the consumer side, and independent of how many 16-bit terms of D the products use (with
+  // d_terms = 1 a bias gradient that is a small difference of large sums would otherwise inherit D's 11-bit rounding).
+  const bool do_bias = with_bias && bt == 0 && kh0 == 0;
   if (producer) {
     // ---- waves 4-7: global -> registers -> split -> LDS, one tile ahead of the consumers --------
     const int ptid = tid - 256;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     // two register sets: the loads of tiles i+2 and i+3 are in flight while tile i+1 is split and
     // stored (one tile of look-ahead left the loads ~1 tile time to land: less than the loaded-memory
     // latency, so the consumers waited at the barrier)
@@ -327,6 +352,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
         const int idx = ptid + 256 * i, px = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
         bf16x4 parts[NS];
         split4f<NS, FMT, 1>(rd[S][i], scD, parts);
+        bsum += rd[S][i];                    // (pixels outside the image were loaded as zeros)
 #pragma unroll
         for (int s = 0; s < DT; ++s) *reinterpret_cast<bf16x4*>(&sD[s * PX * LD + px * LD + c]) = parts[s];
       }
@@ -358,6 +384,25 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
       if (i + 4 < nt) load_tile(t_beg + i + 4, S0);
       __syncthreads();
     }
+    // bias sums: thread (pixel column ptid >> 4, channels 4 (ptid & 15) ..) -> the 16 pixel columns of a channel quad sit
+    // in four lane groups of each of the four staging waves: shuffles inside a wave, then LDS (both images are dead)
+    bsum[0] += __shfl_xor(bsum[0], 16, 64); bsum[1] += __shfl_xor(bsum[1], 16, 64);
+    bsum[2] += __shfl_xor(bsum[2], 16, 64); bsum[3] += __shfl_xor(bsum[3], 16, 64);
+    bsum[0] += __shfl_xor(bsum[0], 32, 64); bsum[1] += __shfl_xor(bsum[1], 32, 64);
+    bsum[2] += __shfl_xor(bsum[2], 32, 64); bsum[3] += __shfl_xor(bsum[3], 32, 64);
+    float* bl = reinterpret_cast<float*>(sm);
+    if (do_bias && lane < 16) *reinterpret_cast<f32x4*>(&bl[(wave - 4) * 64 + lane * 4]) = bsum;
+    __syncthreads();                         // (matched by the consumers' barrier after their tile loop)
+    if (do_bias && wave == 4 && lane < 16) {
+      const int TSb = p.KH * p.KW + 1;
+      float* slab = pslabs + (long)split * p.Cd * TSb * p.Cg;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ai = a0 + lane * 4 + j;
+        const float v = (bl[lane * 4 + j] + bl[64 + lane * 4 + j]) + (bl[128 + lane * 4 + j] + bl[192 + lane * 4 + j]);
+        if (ai < p.Cd) slab[((long)ai * TSb + p.KH * p.KW) * p.Cg] = v;
+      }
+    }
     return;
   }
 
@@ -368,13 +413,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  const bool do_bias = with_bias && bt == 0 && kh0 == 0;
-  f32x16 acc_bias;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc_bias[r] = 0.f;
-  bf16x8 ones;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ones[j] = FMT ? __builtin_bit_cast(__bf16, (_Float16)1.0f) : (__bf16)1.0f;
   const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3, g1 = (lane >> 4) & 1, lh = lane >> 5;
   const int a_off = (8 * lh + q) * LD + wm * 32 + 16 * g1 + 4 * pp;
   const int b_off = (8 * lh + q) * LD + wn * 32 + 16 * g1 + 4 * pp;
@@ -400,13 +438,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
       if (r < TR) {
 #pragma unroll
         for (int s = 0; s < DT; ++s) fa[r % KHB][s] = tr_frag(sD + s * PX * LD, a_off + r * 16 * LD, LD);
-        if (do_bias) {
-#pragma unroll
-          for (int s = DT - 1; s >= 0; --s) {
-            if constexpr (FMT == 0) acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[r % KHB][s], ones, acc_bias, 0, 0, 0);
-            else acc_bias = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fa[r % KHB][s]), __builtin_bit_cast(half8, ones), acc_bias, 0, 0, 0);
-          }
-        }
       }
 #pragma unroll
       for (int kh = 0; kh < KHB; ++kh) {
@@ -430,17 +461,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
     }
     __syncthreads();
   }
+  __syncthreads();                           // (the staging waves' bias sums pass through LDS behind this barrier)
 
   const int T = p.KH * p.KW, li = lane & 31;
   const int TS = T + (with_bias ? 1 : 0);
   float* slab = pslabs + (long)split * p.Cd * TS * p.Cg;
-  if (do_bias && wn == 0 && li == 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (ai < p.Cd) slab[((long)ai * TS + T) * p.Cg] = acc_bias[r] * inv_d;
-    }
-  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int tap = (kh0 + t / KS) * KS + (t % KS);

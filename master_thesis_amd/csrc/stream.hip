@@ -275,8 +275,7 @@ __global__ void warp_fwd_kernel(const float* x, const float* v, const float* gri
 template <int CC>
 __global__ __launch_bounds__(256) void warp_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ v,
                                                         const float* __restrict__ grid, WarpL L, int ac,
-                                                        float* __restrict__ xo, float* __restrict__ vo, int* __restrict__ idx,
-                                                        int tiled) {
+                                                        float* __restrict__ xo, float* __restrict__ vo, int* __restrict__ idx) {
   const int H = L.H, W = L.W;
   const long HW = (long)H * W, HW4 = HW >> 2;
   const long total4 = (long)L.B * L.F * HW4;
@@ -288,17 +287,11 @@ __global__ __launch_bounds__(256) void warp_fwd4_kernel(const float* __restrict_
   // round-robin order fetched every line into several L2s: 2.9x the algorithmic read traffic, PMC FETCH_SIZE.)
   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;      // (the grid is a multiple of 8)
   const long per = (((total4 + 7) >> 3) + 63) & ~63L, q_end = min(total4, (xcd + 1) * per);     // (whole waves)
-  const int tpr = W >> 4;                           // tiled: 16 x 16-pixel tiles per row of tiles
   for (long q = xcd * per + lb * (long)blockDim.x + threadIdx.x; q < q_end; q += (long)nlb * blockDim.x) {
     const int n = (int)(q / HW4);
-    long pix = (q - n * HW4) << 2;
-    if (tiled) {
-      // a wave = one 16 x 16 tile (lane = row l >> 2, pixels 4 (l & 3) ..): under a rotation the gathers of a tile stay
-      // inside ~20 source rows x ~80 bytes, where a 256-pixel row segment crosses 50 rows with 20 bytes in each
-      const int r = (int)(q - n * HW4), wv = r >> 6, l = r & 63;
-      const int tyb = wv / tpr, txb = wv - tyb * tpr;
-      pix = (long)(tyb * 16 + (l >> 2)) * W + txb * 16 + (l & 3) * 4;
-    }
+    // (a 2-D mapping -- one 16 x 16 tile per wave, so that the gathers of a rotated flow stay inside ~20 source rows --
+    // was measured and rejected: 2.8 vs 3.0 TB/s at 256^2, 4.3 vs 5.1 at 64^2, 2.8 vs 2.6 at 512^2)
+    const long pix = (q - n * HW4) << 2;
     const long e = n * HW + pix;
     const int b = n / L.F, f = n - b * L.F;
     const f32x4 g01 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grid + e * 2));
@@ -883,11 +876,9 @@ extern "C" int mt_warp_fwd(const float* x, const float* v, const float* grid, co
                     ((L.ob | L.oc | L.of) & 3) == 0 && (!vo || ((reinterpret_cast<uintptr_t>(vo) & 15) == 0 && ((L.wb | L.wf) & 3) == 0));
   if (vec4) {
     const int g4 = (mt_grid_1d((long)L.B * L.F * L.H * L.W / 4, 256, 8192) + 7) & ~7;
-    static const bool tiled_on = [] { const char* e = getenv("MT355_WARP_TILED"); return !(e && e[0] == '0'); }();   // (lab A/B)
-    const int tiled = (tiled_on && (L.W & 15) == 0 && (L.H & 15) == 0) ? 1 : 0;
-    if (L.C == 3) hipLaunchKernelGGL((warp_fwd4_kernel<3>), dim3(g4), dim3(256), 0, S_(stream), x, v, grid, L, align_corners, xo, vo, idx, tiled);
-    else if (L.C == 1) hipLaunchKernelGGL((warp_fwd4_kernel<1>), dim3(g4), dim3(256), 0, S_(stream), x, v, grid, L, align_corners, xo, vo, idx, tiled);
-    else hipLaunchKernelGGL((warp_fwd4_kernel<0>), dim3(g4), dim3(256), 0, S_(stream), x, v, grid, L, align_corners, xo, vo, idx, tiled);
+    if (L.C == 3) hipLaunchKernelGGL((warp_fwd4_kernel<3>), dim3(g4), dim3(256), 0, S_(stream), x, v, grid, L, align_corners, xo, vo, idx);
+    else if (L.C == 1) hipLaunchKernelGGL((warp_fwd4_kernel<1>), dim3(g4), dim3(256), 0, S_(stream), x, v, grid, L, align_corners, xo, vo, idx);
+    else hipLaunchKernelGGL((warp_fwd4_kernel<0>), dim3(g4), dim3(256), 0, S_(stream), x, v, grid, L, align_corners, xo, vo, idx);
     return mt_check_launch("mt_warp_fwd");
   }
   hipLaunchKernelGGL(warp_fwd_kernel, dim3(mt_grid_1d((long)L.B * L.F * L.H * L.W, 256)), dim3(256), 0, S_(stream), x,
