@@ -267,11 +267,16 @@ __global__ void warp_fwd_kernel(const float* x, const float* v, const float* gri
   }
 }
 
-// Four consecutive output pixels of a row per thread (W % 4 == 0, 16-byte aligned outputs and flow): the flow comes
-// as two 16-byte loads, every output plane leaves as one 16-byte store, and the two corners of a bilinear row that
-// are both inside the image come as ONE 8-byte gather -- 34 memory instructions per four pixels instead of 72, and
-// the gathers of all four pixels are in flight together.  The coordinate arithmetic is the same expression for
-// expression as warp_fwd_kernel (stream.hip is built with -ffp-contract=off): indices stay bit-exact.
+// Four output pixels per thread, INTERLEAVED over the wave: a wave owns 256 consecutive pixels of one image and lane l
+// takes pixels l, l + 64, l + 128, l + 192 of them.  Every memory instruction of a wave then touches consecutive
+// addresses (the flow: 8 bytes per lane; a gather: the source pixels under 64 neighbouring output pixels; a store: 4
+// bytes per lane), which is what the address coalescer wants, and the gathers of a thread's four pixels -- 24 eight-byte
+// loads: the two corners of a bilinear row that are both inside the image come as ONE load -- are all in flight together.
+// (History, 1024 pairs at 256 x 256: one pixel per thread, 18 instructions per 64 pixels: 1.98 TB/s; four CONSECUTIVE
+// pixels per thread with 16-byte flow loads / stores: 3.0 TB/s, bound by the texture addresser -- a gather whose lanes
+// sit 16 bytes apart costs it a cycle per lane (PMC: 57 % of the wave cycles waiting at 71 % L2 hits and no over-fetch).)
+// The coordinate arithmetic is that of warp_fwd_kernel expression for expression (stream.hip is built with
+// -ffp-contract=off): indices stay bit-exact.
 template <int CC>
 __global__ __launch_bounds__(256) void warp_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ v,
                                                         const float* __restrict__ grid, WarpL L, int ac,
@@ -280,29 +285,28 @@ __global__ __launch_bounds__(256) void warp_fwd4_kernel(const float* __restrict_
   const long HW = (long)H * W, HW4 = HW >> 2;
   const long total4 = (long)L.B * L.F * HW4;
   const int C = CC > 0 ? CC : L.C;
+  const int lane = threadIdx.x & 63;
   // Blocks are dealt round-robin over the 8 XCDs (each with its own L2).  A row of output pixels gathers along a
   // slanted line of the source (a 0.2 rad rotation crosses 50 source rows in 256 pixels), so a cache line it touches is
   // shared with the output rows above and below: every XCD therefore takes ONE contiguous eighth of the pixels and its
-  // blocks walk it side by side -- the rows that share lines are in flight on the same L2 at the same time.  (Plain
-  // round-robin order fetched every line into several L2s: 2.9x the algorithmic read traffic, PMC FETCH_SIZE.)
+  // blocks walk it side by side -- the rows that share lines are in flight on the same L2 at the same time.
   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = gridDim.x >> 3;      // (the grid is a multiple of 8)
   const long per = (((total4 + 7) >> 3) + 63) & ~63L, q_end = min(total4, (xcd + 1) * per);     // (whole waves)
   for (long q = xcd * per + lb * (long)blockDim.x + threadIdx.x; q < q_end; q += (long)nlb * blockDim.x) {
-    const int n = (int)(q / HW4);
-    // (a 2-D mapping -- one 16 x 16 tile per wave, so that the gathers of a rotated flow stay inside ~20 source rows --
-    // was measured and rejected: 2.8 vs 3.0 TB/s at 256^2, 4.3 vs 5.1 at 64^2, 2.8 vs 2.6 at 512^2)
-    const long pix = (q - n * HW4) << 2;
-    const long e = n * HW + pix;
+    const long qw = q - lane;                       // the wave's first group of four: 256 pixels from pixel 4 qw on
+    const int n = (int)(qw / HW4);                  // (HW % 256 == 0: a wave never straddles two images)
+    const long pix0 = ((qw - n * HW4) << 2) + lane;
+    const long e0 = n * HW + pix0;
     const int b = n / L.F, f = n - b * L.F;
-    const f32x4 g01 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grid + e * 2));
-    const f32x4 g23 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grid + e * 2 + 4));
-    const float gx[4] = {g01[0], g01[2], g23[0], g23[2]}, gy[4] = {g01[1], g01[3], g23[1], g23[3]};
+    f32x2 g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(grid + (e0 + 64 * k) * 2));
     int x0[4], y0[4], nx[4], ny[4];
     float nw[4], ne[4], sw[4], se[4];
     unsigned ok[4];                        // bit 0: x0, 1: x1, 2: y0, 3: y1 inside; bit 4: nearest inside; bit 5: corners finite
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float ix = unnorm(gx[k], W, ac), iy = unnorm(gy[k], H, ac);
+      const float ix = unnorm(g[k][0], W, ac), iy = unnorm(g[k][1], H, ac);
       const float fx = floorf(ix), fy = floorf(iy);
       x0[k] = coord_int(fx); y0[k] = coord_int(fy);
       const int x1 = x0[k] + 1, y1 = y0[k] + 1;
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void warp_fwd4_kernel(const float* __restrict_
       ok[k] |= (fabsf(fx) < 1e9f && fabsf(fy) < 1e9f) ? 32u : 0u;
     }
     const float* xp = x + b * L.xb + f * L.xf;
-    float* op = xo + b * L.ob + f * L.of + pix;
+    float* op = xo + b * L.ob + f * L.of + pix0;
     // One bilinear row = ONE unconditional 8-byte gather at a clamped address (columns xc, xc + 1 of a clamped row):
     // the corner that lies inside the image is one of the two values, a corner outside adds nothing to the sum.
     // No divergent control flow: the 24 gathers of a thread's four pixels are all in flight together.
@@ -337,7 +341,6 @@ __global__ __launch_bounds__(256) void warp_fwd4_kernel(const float* __restrict_
         __builtin_memcpy(&top[k], pl + rt[k], 8);
         __builtin_memcpy(&bot[k], pl + rb[k], 8);
       }
-      f32x4 o;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const bool lo = x0[k] == xc[k];          // x0 is the first value of the pair (else x0 = W - 1: the second; x0 = -1: x1 is the first)
@@ -349,28 +352,26 @@ __global__ __launch_bounds__(256) void warp_fwd4_kernel(const float* __restrict_
         if ((ok[k] & 6u) == 6u) t += tr * ne[k];
         if ((ok[k] & 9u) == 9u) t += bl * sw[k];
         if ((ok[k] & 10u) == 10u) t += br * se[k];
-        o[k] = t;
+        __builtin_nontemporal_store(t, op + cc * L.oc + 64 * k);
       }
-      __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(op + cc * L.oc));
     }
     if (vo) {
       const float* vp = v + b * L.vb + f * L.vf;
-      f32x4 o;
+      float* wp = vo + b * L.wb + f * L.wf + pix0;
+      float t[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float t = vp[(long)max(ny[k], 0) * W + max(nx[k], 0)];
-        o[k] = (ok[k] & 16u) ? t : 0.f;
-      }
-      __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(vo + b * L.wb + f * L.wf + pix));
+      for (int k = 0; k < 4; ++k) t[k] = vp[(long)max(ny[k], 0) * W + max(nx[k], 0)];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) __builtin_nontemporal_store((ok[k] & 16u) ? t[k] : 0.f, wp + 64 * k);
     }
     if (idx) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const bool cin = (ok[k] & 32u) != 0;
-        idx[(e + k) * 4 + 0] = cin ? y0[k] : INT_MIN;
-        idx[(e + k) * 4 + 1] = cin ? x0[k] : INT_MIN;
-        idx[(e + k) * 4 + 2] = ny[k];
-        idx[(e + k) * 4 + 3] = nx[k];
+        idx[(e0 + 64 * k) * 4 + 0] = cin ? y0[k] : INT_MIN;
+        idx[(e0 + 64 * k) * 4 + 1] = cin ? x0[k] : INT_MIN;
+        idx[(e0 + 64 * k) * 4 + 2] = ny[k];
+        idx[(e0 + 64 * k) * 4 + 3] = nx[k];
       }
     }
   }
@@ -871,9 +872,8 @@ extern "C" int mt_warp_fwd(const float* x, const float* v, const float* grid, co
   MT_REQUIRE(x && grid && xo, "mt_warp_fwd: null pointer");
   MT_REQUIRE((v == nullptr) == (vo == nullptr), "mt_warp_fwd: v and vo must come together");
   MT_REQUIRE((reinterpret_cast<uintptr_t>(grid) & 7) == 0, "mt_warp_fwd: grid must be 8-byte aligned");
-  // four pixels per thread when rows are whole float4s and everything that is read / written as a vector is aligned
-  const bool vec4 = (L.W & 3) == 0 && L.W >= 4 && (long)L.H * L.W < (1L << 31) && (reinterpret_cast<uintptr_t>(grid) & 15) == 0 && (reinterpret_cast<uintptr_t>(xo) & 15) == 0 &&
-                    ((L.ob | L.oc | L.of) & 3) == 0 && (!vo || ((reinterpret_cast<uintptr_t>(vo) & 15) == 0 && ((L.wb | L.wf) & 3) == 0));
+  // four pixels per thread (interleaved over the wave) when an image is a whole number of 256-pixel wave loads
+  const bool vec4 = L.W >= 2 && ((long)L.H * L.W & 255) == 0 && (long)L.H * L.W < (1L << 31);
   if (vec4) {
     const int g4 = (mt_grid_1d((long)L.B * L.F * L.H * L.W / 4, 256, 8192) + 7) & ~7;
     if (L.C == 3) hipLaunchKernelGGL((warp_fwd4_kernel<3>), dim3(g4), dim3(256), 0, S_(stream), x, v, grid, L, align_corners, xo, vo, idx);
