@@ -554,7 +554,7 @@ def run_rank(args):
         # 1-D Winograd F(2,3) (conv_halo_wino.hip) issues 2/3 of the direct form's products (F(2,5) kernels: 6/10):
         # its ceiling in ALGORITHMIC FLOP/s is the MFMA peak / products x that saving, and frac against THAT is the
         # fraction of the matrix pipe's peak the executed MFMAs use (frac must not be able to pass 1)
-        saving = 5.0 / 3.0 if 'wino25' in name else (1.5 if 'wino' in name else 1.0)
+        saving = 2.0 if 'wino43' in name else (5.0 / 3.0 if 'wino25' in name else (1.5 if 'wino' in name else 1.0))
         peak = PEAK_FP32_MFMA_TFLOPS if per == 1 else PEAK_16BIT_MFMA_TFLOPS / per * saving
         note = ('achieved = ALGORITHMIC conv FLOP (2*N*H*W*Cin*Cout*k*k per launch) / kernel time (HIP events around every '
                 f'launch of one eager step); peak = dense 16-bit MFMA peak {PEAK_16BIT_MFMA_TFLOPS:.0f} TFLOP/s / {per} MFMA '

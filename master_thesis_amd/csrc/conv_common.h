@@ -404,6 +404,54 @@ __device__ __forceinline__ void pack_halo_wino_body(const float* src, int A, int
   }
 }
 
+// Winograd F(4,3) weights of igemm_wino43_kernel (conv_halo_wino43.hip), U = G g[ky][:], in MFMA fragment order:
+// dst[tap 18 = ky*6 + xi][chunk][ntile][wn 4][kstep 2][plane 2][lane 64][8], lane (li, lh) holds
+// U[ky][xi][a = (ntile*4 + wn)*32 + li][b = chunk*32 + kstep*16 + 8*lh + j]   (taps flipped first when `flip`)
+__device__ __forceinline__ void pack_halo_wino43_body(const float* src, int A, int B, long sa, long sb, long st, __bf16* dst,
+                                                      int nchunk, int ntile, int flip, const float* wamax, int nchunk_total,
+                                                      int ch_off) {
+  const float sc = wamax ? pow2_scale(*wamax) : 1.f;
+  constexpr int WN = 4;
+  const long total = (long)18 * nchunk * ntile * WN * 2 * 64 * 8;      // elements per plane
+  for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7), lane = (int)((e >> 3) & 63), ks = (int)((e >> 9) & 1);
+    long r = e >> 10;
+    const int wv = (int)(r % WN); r /= WN;
+    const int nt = (int)(r % ntile); r /= ntile;
+    const int ch = (int)(r % nchunk);
+    const int t = (int)(r / nchunk);
+    const int ky = t / 6, xi = t - ky * 6;
+    const int a = (nt * WN + wv) * 32 + (lane & 31);
+    const int b = ch * 32 + ks * 16 + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (a < A && b < B) {
+      const float* g = src + a * sa + b * sb;
+      const float g0 = g[(flip ? 8 - (ky * 3 + 0) : ky * 3 + 0) * st];
+      const float g1 = g[(flip ? 8 - (ky * 3 + 1) : ky * 3 + 1) * st];
+      const float g2 = g[(flip ? 8 - (ky * 3 + 2) : ky * 3 + 2) * st];
+      switch (xi) {
+        case 0: v = 0.25f * g0; break;
+        case 1: v = -(1.f / 6.f) * ((g0 + g2) + g1); break;
+        case 2: v = -(1.f / 6.f) * ((g0 + g2) - g1); break;
+        case 3: v = (1.f / 24.f) * ((g0 + 4.f * g2) + 2.f * g1); break;
+        case 4: v = (1.f / 24.f) * ((g0 + 4.f * g2) - 2.f * g1); break;
+        default: v = g2; break;
+      }
+    }
+    __bf16* o = dst + ((((((long)t * nchunk_total + ch_off + ch) * ntile + nt) * WN + wv) * 2 + ks) * 2) * 512 + lane * 8 + j;
+    if (wamax) {
+      v *= sc;
+      const _Float16 h = (_Float16)v;
+      o[0] = __builtin_bit_cast(__bf16, h);
+      o[512] = __builtin_bit_cast(__bf16, (_Float16)(v - (float)h));
+    } else {
+      const __bf16 h = (__bf16)v;
+      o[0] = h;
+      o[512] = (__bf16)(v - (float)h);
+    }
+  }
+}
+
 // Winograd F(2,5) weights of igemm_wino25_kernel (conv_halo_wino25.hip), U = G g[ky][:], in MFMA fragment order:
 // dst[tap 30 = ky*6 + xi][chunk][ntile][wn 4][kstep 2][plane 2][lane 64][8], lane (li, lh) holds
 // U[ky][xi][a = (ntile*4 + wn)*32 + li][b = chunk*32 + kstep*16 + 8*lh + j]   (taps flipped first when `flip`)

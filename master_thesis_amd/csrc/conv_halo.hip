@@ -368,6 +368,10 @@ __host__ __device__ inline int halo_ck(int cin_p, int ns) { return (ns == 3 || (
 bool halo_wino_enabled();                                            // conv_halo_wino.hip
 bool halo_winox_wanted(int cin_p, int cout_p, int T);
 void mt_halo_wino_launch(const void* convk, int fmt, void* stream);
+bool halo_wino43_wanted(int cin_p, int cout_p, int T, int f16);      // conv_halo_wino43.hip
+void mt_halo_wino43_launch(const void* convk, void* stream);
+void mt_pack_halo_wino43_launch(const float* src, int A, int B, long sa, long sb, long st, void* dst, int nchunk, int ntile,
+                                int flip, const float* wamax, int nchunk_total, int ch_off, void* stream);
 bool halo_wino25_wanted(int cin_p, int cout_p, int T, int f16);      // conv_halo_wino25.hip
 void mt_halo_wino25_launch(const void* convk, int fmt, void* stream);
 void mt_pack_halo_wino25_launch(const float* src, int A, int B, long sa, long sb, long st, void* dst, int nchunk, int ntile,
@@ -383,6 +387,10 @@ void launch_halo(const ConvK& k, hipStream_t s) {
   const int tiles_y = (k.Ho + 7) / 8, tiles_x = (k.Wo + 15) / 16;
   const unsigned nt = (unsigned)k.N * tiles_y * tiles_x;
   if constexpr (NS == 2) {
+    if (KS == 3 && halo_wino43_wanted(k.C, k.Co, 9, FMT)) {      // 1-D Winograd F(4,3), 128-wide tiles, fp16 split
+      mt_halo_wino43_launch(&k, s);
+      return;
+    }
     if (halo_wino_wanted(k.C, k.Co, KS * KS)) {
       mt_halo_wino_launch(&k, FMT, s);
       return;
@@ -550,7 +558,9 @@ __global__ void weight_pack_jobs_kernel(const mt_pack_job* jobs) {
   const int BN = j.AP > 64 ? 128 : (j.AP > 32 ? 64 : 32);
   const int nchunk = (j.BP + CK - 1) / CK, ntile = (j.AP + BN - 1) / BN;
   const int nchunk_total = (j.BP_total + CK - 1) / CK, ch_off = j.b_off / CK;
-  if (j.frag_order == 5)
+  if (j.frag_order == 6)
+    pack_halo_wino43_body(j.src, j.A, j.B, j.sa, j.sb, j.st, dst, nchunk, ntile, j.flip, j.w_amax, nchunk_total, ch_off);
+  else if (j.frag_order == 5)
     pack_halo_wino25_body(j.src, j.A, j.B, j.sa, j.sb, j.st, dst, nchunk, ntile, j.flip, j.w_amax, nchunk_total, ch_off);
   else if (j.frag_order == 2)
     pack_halo_wino_body(j.src, j.A, j.B, j.sa, j.sb, j.st, dst, nchunk, ntile, j.flip, j.w_amax, nchunk_total, ch_off, BN / 32);
@@ -574,7 +584,8 @@ __global__ void absmax_segments_kernel(const mt_amax_seg* segs) {
 extern "C" int64_t mt_weight_pack_halo_elems(int32_t AP, int32_t BP, int32_t T, int32_t precision) {
   const int NS = precision == MT_PREC_BF16X6 ? 3 : 2, CK = halo_ck(BP, NS), LD = CK + 8;
   const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);
-  if (NS == 2 && halo_wino_wanted(BP, AP, T)) T = 12;      // the (ky, xi) "taps" of the Winograd image (fragment order)
+  if (NS == 2 && halo_wino43_wanted(BP, AP, T, precision == MT_PREC_F16X3)) T = 18;   // F(4,3): 3 kernel rows x 6 xi
+  else if (NS == 2 && halo_wino_wanted(BP, AP, T)) T = 12;      // the (ky, xi) "taps" of the Winograd image (fragment order)
   else if (NS == 2 && halo_wino25_wanted(BP, AP, T, precision == MT_PREC_F16X3)) T = 30;   // F(2,5): 5 kernel rows x 6 xi
   return (int64_t)T * ((BP + CK - 1) / CK) * ((AP + BN - 1) / BN) * NS * BN * LD;
 }
@@ -599,6 +610,10 @@ static int pack_halo_impl(const float* src, int32_t A, int32_t B, int32_t T, int
                        static_cast<hipStream_t>(stream), src, A, B, (long)sa, (long)sb, (long)st,
                        reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, w_amax, nchunk_total, ch_off, BN / 32);
     return mt_check_launch("mt_weight_pack_halo(wino)");
+  }
+  if (NS == 2 && halo_wino43_wanted(BP_total, AP, T, precision == MT_PREC_F16X3)) {   // F(4,3)-transformed fragments for igemm_wino43_kernel
+    mt_pack_halo_wino43_launch(src, A, B, (long)sa, (long)sb, (long)st, dst, nchunk, ntile, flip, w_amax, nchunk_total, ch_off, stream);
+    return mt_check_launch("mt_weight_pack_halo(wino43)");
   }
   if (NS == 2 && halo_wino25_wanted(BP_total, AP, T, precision == MT_PREC_F16X3)) {   // F(2,5)-transformed fragments for igemm_wino25_kernel
     mt_pack_halo_wino25_launch(src, A, B, (long)sa, (long)sb, (long)st, dst, nchunk, ntile, flip, w_amax, nchunk_total, ch_off, stream);
@@ -633,6 +648,7 @@ extern "C" int mt_weight_pack_halo_part(const float* src, int32_t A, int32_t B, 
 
 extern "C" int32_t mt_weight_pack_halo_frag_order(int32_t AP, int32_t BP_total, int32_t T, int32_t precision) {
   if (precision == MT_PREC_BF16X6) return 0;
+  if (halo_wino43_wanted(BP_total, AP, T, precision == MT_PREC_F16X3)) return 6;        // 6: F(4,3) fragments (igemm_wino43_kernel)
   if (halo_wino25_wanted(BP_total, AP, T, precision == MT_PREC_F16X3)) return 5;        // 5: F(2,5) fragments (igemm_wino25_kernel)
   if (halo_wino_wanted(BP_total, AP, T)) return 2;          // 2: Winograd F(2,3) fragments
   if (!halo_rb_wanted(BP_total, AP)) return 0;

@@ -102,6 +102,7 @@ WGRAD_D_TERMS = int(os.environ.get('MT355_WGRAD_D_TERMS', '1'))
 HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_enabled() in conv_halo_wino.hip
 HALO_WINO25 = os.environ.get('MT355_WINO25', '1') != '0'  # mirrors halo_wino25_enabled() in conv_halo_wino25.hip
 HALO_WINOX = os.environ.get('MT355_WINOX', '1') != '0'    # mirrors halo_winox_enabled() in conv_halo_wino.hip
+HALO_WINO43 = os.environ.get('MT355_WINO43', '1') != '0'  # mirrors halo_wino43_enabled() in conv_halo_wino43.hip
 WINOX64 = int(os.environ.get('MT355_WINOX64', '128'))     # ... and its threshold for 64-wide layers (lab)
 TINY_OUT = os.environ.get('MT355_TINY_OUT', '1') != '0'   # ... and for 128 -> 1 / 2 channel layers (A/B switch)
 TINY = os.environ.get('MT355_TINY', '1') != '0'           # fp32 VALU kernels for layers with <= 4 channels on one side (conv_tiny.hip)
@@ -138,6 +139,8 @@ def _kname(template, k, co=0, ho=0, cin_p=0, ups=0):
     if (k == 5 and HALO_WINO25 and '{rbw}' in template and ',f16' in template and co > 64 and cin_p > 32 and cin_p % 32 == 0
             and ups == 0):
         return 'igemm_wino25_kernel<f16>'
+    if k == 3 and HALO_WINO43 and '{rbw}' in template and ',f16' in template and co > 64 and cin_p > 32:
+        return 'igemm_wino43_kernel<f16>'
     if (k == 3 and HALO_WINO and HALO_WINOX and 'igemm_halo' in template and cin_p > 32 and '3,bf16' not in template
             and (0 < co <= 32 or (co <= 64 and cin_p >= WINOX64))):          # the xi-split Winograd kernel (two-term splits, <= 64 output channels)
         return 'igemm_winox_kernel<%s,%d>' % ('f16' if 'f16' in template.replace('bf16', '') else 'bf16', 2 if co > 32 else 1)
