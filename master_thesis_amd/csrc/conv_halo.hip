@@ -604,16 +604,17 @@ static int pack_halo_impl(const float* src, int32_t A, int32_t B, int32_t T, int
   const int BN = AP > 64 ? 128 : (AP > 32 ? 64 : 32);        // the n-tile igemm_halo uses for Co = AP
   const int nchunk = (BP + CK - 1) / CK, ntile = (AP + BN - 1) / BN;
   const int nchunk_total = (BP_total + CK - 1) / CK, ch_off = b_off / CK;
+  // (the same precedence as mt_weight_pack_halo_frag_order: F(4,3) before F(2,3))
+  if (NS == 2 && halo_wino43_wanted(BP_total, AP, T, precision == MT_PREC_F16X3)) {   // F(4,3)-transformed fragments for igemm_wino43_kernel
+    mt_pack_halo_wino43_launch(src, A, B, (long)sa, (long)sb, (long)st, dst, nchunk, ntile, flip, w_amax, nchunk_total, ch_off, stream);
+    return mt_check_launch("mt_weight_pack_halo(wino43)");
+  }
   if (NS == 2 && halo_wino_wanted(BP_total, AP, T)) {     // Winograd-transformed fragments for igemm_halo_wino_kernel
     const long tot = (long)12 * nchunk * ntile * (BN / 32) * 1024;
     hipLaunchKernelGGL(weight_pack_halo_wino_kernel, dim3(mt_grid_1d(tot, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), src, A, B, (long)sa, (long)sb, (long)st,
                        reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, w_amax, nchunk_total, ch_off, BN / 32);
     return mt_check_launch("mt_weight_pack_halo(wino)");
-  }
-  if (NS == 2 && halo_wino43_wanted(BP_total, AP, T, precision == MT_PREC_F16X3)) {   // F(4,3)-transformed fragments for igemm_wino43_kernel
-    mt_pack_halo_wino43_launch(src, A, B, (long)sa, (long)sb, (long)st, dst, nchunk, ntile, flip, w_amax, nchunk_total, ch_off, stream);
-    return mt_check_launch("mt_weight_pack_halo(wino43)");
   }
   if (NS == 2 && halo_wino25_wanted(BP_total, AP, T, precision == MT_PREC_F16X3)) {   // F(2,5)-transformed fragments for igemm_wino25_kernel
     mt_pack_halo_wino25_launch(src, A, B, (long)sa, (long)sb, (long)st, dst, nchunk, ntile, flip, w_amax, nchunk_total, ch_off, stream);
