@@ -162,8 +162,8 @@ def test_conv_forward_backward(mt, case, precision):
 
 @pytest.mark.parametrize('case', [(2, 32, 32, 128, 128), (1, 24, 40, 64, 64), (2, 16, 16, 256, 256), (1, 19, 27, 128, 256)])
 def test_conv3x3_f16x3_is_fp32_grade(mt, case):
-    """The default arithmetic on the hot 3 x 3 stride-1 layers (split fp16 operands, and on the
-    register-B shapes the 1-D Winograd F(2,3) transform) against an fp64 convolution: forward
+    """The default arithmetic on the hot 3 x 3 stride-1 layers (split fp16 operands under the 1-D Winograd
+    transforms: F(4,3) for 128-wide tiles, F(2,3) for 64-wide ones) against an fp64 convolution: forward
     and backward-data stay at fp32 rounding level, far inside the 1e-3 bar."""
     from master_thesis_amd import engine as E
     n, h, w, cin, cout = case
@@ -185,7 +185,9 @@ def test_conv3x3_f16x3_is_fp32_grade(mt, case):
     e_bwd = float((xg.grad.cpu().double() - x64.grad).abs().max() / x64.grad.abs().max())
     e_ref = float((y32.double() - y64.detach()).abs().max() / y64.detach().abs().max())
     print(f'3x3 {case}: fwd {e_fwd:.2e} bwd {e_bwd:.2e} (torch fp32 {e_ref:.2e})')
-    assert e_fwd < 3e-6 and e_bwd < 3e-6, (e_fwd, e_bwd, e_ref)
+    # measured: F(2,3) (64-wide tiles, and every layer in rounds 1-2) 3e-7 .. 1e-6; F(4,3) (128-wide tiles, six
+    # interpolation points, round 3) 1.5e-6 .. 3.4e-6; torch's own fp32 convolution 2.6e-7 .. 2.8e-7
+    assert e_fwd < 5e-6 and e_bwd < 5e-6, (e_fwd, e_bwd, e_ref)
 
 
 @pytest.mark.parametrize('case', [(4, 64, 64, 128, 128, 3), (4, 64, 64, 128, 128, 5), (64, 16, 16, 256, 256, 3)])
