@@ -103,7 +103,7 @@ HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_en
 HALO_WINO25 = os.environ.get('MT355_WINO25', '1') != '0'  # mirrors halo_wino25_enabled() in conv_halo_wino25.hip
 HALO_WINOX = os.environ.get('MT355_WINOX', '1') != '0'    # mirrors halo_winox_enabled() in conv_halo_wino.hip
 HALO_WINO43 = os.environ.get('MT355_WINO43', '1') != '0'  # mirrors halo_wino43_enabled() in conv_halo_wino43.hip
-WINOX64 = int(os.environ.get('MT355_WINOX64', '128'))     # ... and its threshold for 64-wide layers (lab)
+WINOX64 = 128                                             # ... 64-wide layers from 128 gathered channels on
 TINY_OUT = os.environ.get('MT355_TINY_OUT', '1') != '0'   # ... and for 128 -> 1 / 2 channel layers (A/B switch)
 TINY = os.environ.get('MT355_TINY', '1') != '0'           # fp32 VALU kernels for layers with <= 4 channels on one side (conv_tiny.hip)
 
