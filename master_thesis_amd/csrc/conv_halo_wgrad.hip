@@ -7,6 +7,10 @@
 #ifndef MT_WGPC_PAD
 #define MT_WGPC_PAD 32
 #endif
+// split form of the staging waves (conv_common.h: split4f SHADOW): 1 = instructions that do not share the matrix pipe
+#ifndef MT_WGPC_SHADOW
+#define MT_WGPC_SHADOW 1
+#endif
 #include "conv_common.h"
 
 // ------------------------------------------------------------ wgrad (halo) --
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
       for (int i = 0; i < RD; ++i) {
         const int idx = ptid + 256 * i, px = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
         bf16x4 parts[NS];
-        split4f<NS, FMT, 1>(rd[S][i], scD, parts);
+        split4f<NS, FMT, MT_WGPC_SHADOW>(rd[S][i], scD, parts);
         bsum += rd[S][i];                    // (pixels outside the image were loaded as zeros)
 #pragma unroll
         for (int s = 0; s < DT; ++s) *reinterpret_cast<bf16x4*>(&sD[s * PX * LD + px * LD + c]) = parts[s];
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
         const int idx = ptid + 256 * i, gpx = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
         if (idx < NG4) {
           bf16x4 parts[NS];
-          split4f<NS, FMT, 1>(rg[S][i], scG, parts);
+          split4f<NS, FMT, MT_WGPC_SHADOW>(rg[S][i], scG, parts);
 #pragma unroll
           for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sG[s * GP * LD + gpx * LD + c]) = parts[s];
         }
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_thin_kernel(WgK p, int tiles_y, 
       for (int i = 0; i < RD; ++i) {
         const int idx = ptid + 256 * i, px = idx / (CH / 4), c = (idx % (CH / 4)) * 4;
         bf16x4 parts[NS];
-        split4f<NS, FMT, 1>(rd[S][i], scD, parts);
+        split4f<NS, FMT, MT_WGPC_SHADOW>(rd[S][i], scD, parts);
 #pragma unroll
         for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sD[s * PX * LD + px * LD + c]) = parts[s];
       }
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_thin_kernel(WgK p, int tiles_y, 
         const int idx = ptid + 256 * i;
         if (idx < NG4) {
           bf16x4 parts[NS];
-          split4f<NS, FMT, 1>(rg[S][i], scG, parts);
+          split4f<NS, FMT, MT_WGPC_SHADOW>(rg[S][i], scG, parts);
 #pragma unroll
           for (int s = 0; s < NS; ++s) *reinterpret_cast<bf16x4*>(&sG[s * GP * LDG + (idx >> 2) * LDG + cg4]) = parts[s];
         }
