@@ -165,8 +165,12 @@ class RRDBNetFn(torch.autograd.Function):
         # every buffer up front (main stream); without a backward to feed, four rotate (an RRDB's input is read
         # again by the residual after its third block)
         pool = [torch.empty((n, h, w, cw), device=dev, dtype=torch.float32) for _ in range(nbuf if keep else 4)]
-        amax = [torch.zeros((nbuf,), device=dev, dtype=torch.float32) for _ in range(nc)] if f16 else [None] * nc
         halves = [slice(c * (n // nc), (c + 1) * (n // nc)) for c in range(nc)]
+        # one launch per dense block (mt_rdb_fwd) where its geometry fits: the kernel keeps the input's max|.| (slot i) apart
+        # from the running maximum of what it writes into the buffer (slot nbuf + i)
+        fused = E.rdb_fused_eligible(n // nc, h, w, nf, gc)
+        amax = [torch.zeros((2 * nbuf if fused else nbuf,), device=dev, dtype=torch.float32) for _ in range(nc)] if f16 else [None] * nc
+        scratch = [E.rdb_scratch(n // nc, h, w, dev) for _ in range(nc)] if fused else None
         # touch every weight pack on the main stream (first use makes it: the chains must only ever read them)
         prec = E.eff_precision(True)
         for k in range(nb):
@@ -183,6 +187,12 @@ class RRDBNetFn(torch.autograd.Function):
             sl = halves[c]
             buf, nxt = pool[idx % len(pool)][sl], pool[(idx + 1) % len(pool)][sl]
             key = f'rrdb_trunk.{k}.rdb{j}.'
+            if fused:
+                done = E.rdb_forward([P[f'{key}conv{i}.weight'] for i in range(1, 6)], [P[f'{key}conv{i}.bias'] for i in range(1, 6)],
+                                     buf, nxt, a_(c, idx), amax[c][nbuf + idx: nbuf + idx + 1] if f16 else None, a_(c, idx + 1),
+                                     scratch[c], nf, gc)
+                assert done, 'mt_rdb_fwd refused a geometry engine.rdb_fused_eligible accepted'
+                return
             for i in range(1, 5):
                 conv(f'{key}conv{i}', buf[..., :nf + (i - 1) * gc], nf + (i - 1) * gc, gc, act=LRELU,
                      out=buf[..., nf + (i - 1) * gc: nf + i * gc], x_amax=a_(c, idx), y_amax=a_(c, idx))
@@ -209,6 +219,8 @@ class RRDBNetFn(torch.autograd.Function):
                         E.absmax_into(cur, a_(c, idx))
         RRDBNetFn._join(streams)
         merged = torch.stack(amax).amax(0) if f16 else None
+        if f16 and fused:                  # whole buffer: max(input, what the block wrote into it)
+            merged = torch.maximum(merged[:nbuf], merged[nbuf:])
         bufs = [(pool[i], merged[i:i + 1] if f16 else None) for i in range(nbuf - 1)] if keep else [None]
         last = pool[(nbuf - 1) % len(pool)]
         return last, (merged[nbuf - 1: nbuf] if f16 else None), bufs
