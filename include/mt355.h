@@ -132,16 +132,6 @@ typedef struct {
 } mt_conv;
 
 int mt_conv_run(const mt_conv* d, void* stream);
-/* One ResidualDenseBlock5C forward (model_chn.py:588-623) as ONE launch: descs[0..3] = the four growth convs as
- * mt_conv_run would take them (x = channels [0, 64 + 32 i) of the block buffer, y = channels [64 + 32 i, + 32) of the same
- * buffer, LeakyReLU), descs[4] = conv5 (x = all 192 channels, y = the next block's first 64 channels, res / alpha / beta =
- * the residual).  A thread block owns a band of 8 rows of one image and recomputes the rows of its neighbours' bands that
- * its later layers read (no communication between blocks); those rows live in `scratch` (mt_rdb_scratch_floats floats).
- * `buf_amax` (F16X3): the block buffer's running max|.|, raised by what the growth convs write; descs[4].y_amax is raised
- * by conv5.  Returns 1 when the launch was taken, 0 when the geometry is not this kernel's (run the layers one by one),
- * a negative mt_status on errors. */
-int mt_rdb_fwd(const mt_conv* descs, float* scratch, int64_t scratch_floats, float* buf_amax, void* stream);
-int64_t mt_rdb_scratch_floats(int32_t N, int32_t H, int32_t W);
 /* The same call for stride-1 3x3 "same" layers whose gathered tensor has at most FOUR real channels and whose
  * output has 64 or 128 (model_vgg.py:40 conv1_1, the 1 -> 128 entry of SeparableConv4d model_dfpn.py:596-605,
  * and the backward-data of the 128 -> 1 / 128 -> 2 exits, model_dfpn.py:604,710): plain fp32 on the VALU, no

@@ -77,8 +77,6 @@ SIGNATURES = {
     'mt_version': [],
     'mt_last_error': [],
     'mt_conv_run': [_P(Conv), _vp],
-    'mt_rdb_fwd': [_P(Conv), _vp, i64, _vp, _vp],
-    'mt_rdb_scratch_floats': [i32, i32, i32],
     'mt_conv_run_naive': [_P(Conv), _vp],
     'mt_conv_tiny_in_run': [_P(Conv), _vp, i32, i64, i64, i64, i32, _vp],
     'mt_conv_tiny_out_run': [_P(Conv), _vp, i32, i64, i64, i64, i32, i32, i32, _vp],
@@ -135,7 +133,7 @@ SIGNATURES = {
     'mt_allreduce_sum_f32': [_vp, _vp, i64, _vp],
 }
 _RESTYPES = {'mt_last_error': C.c_char_p, 'mt_wgrad_slab_floats': i64, 'mt_weight_pack_halo_elems': i64,
-             'mt_weight_pack_planes_elems': i64, 'mt_rdb_scratch_floats': i64}
+             'mt_weight_pack_planes_elems': i64}
 
 _lib = None
 

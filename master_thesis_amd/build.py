@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libmt355.so')
-SOURCES = [('conv.hip', []), ('conv_halo.hip', []), ('conv_halo_wgrad.hip', []), ('conv_halo_wino.hip', []), ('conv_halo_wino25.hip', []), ('conv_halo_wino43.hip', []), ('conv_rdb.hip', []), ('conv_halo_planes.hip', []), ('conv_tiny.hip', []), ('stream.hip', ['-ffp-contract=off']),
+SOURCES = [('conv.hip', []), ('conv_halo.hip', []), ('conv_halo_wgrad.hip', []), ('conv_halo_wino.hip', []), ('conv_halo_wino25.hip', []), ('conv_halo_wino43.hip', []), ('conv_halo_planes.hip', []), ('conv_tiny.hip', []), ('stream.hip', ['-ffp-contract=off']),
            ('metrics.hip', []), ('api.cpp', []), ('comm.cpp', [])]
 
 

@@ -577,47 +577,6 @@ def _fill_forward_desc(d, spec, xv, w, b, out, res, alpha, beta, x_amax, y_amax,
     return (packed, wa, pb, keep, keep_y)
 
 
-RDB_FUSED = os.environ.get('MT355_RDB_FUSED', '1') != '0'     # one launch per dense block forward (mt_rdb_fwd)
-
-
-def rdb_fused_eligible(n, h, w, nf, gc):
-    """Mirror of mt_rdb_fwd's geometry test (the caller picks its scale-scalar scheme before the first launch)."""
-    return (RDB_FUSED and USE_HALO and HALO_WINO and HALO_WINOX and PRECISION in ('f16x3', 'bf16x3') and nf == 64 and gc == 32
-            and h % 8 == 0 and w % 16 == 0 and h >= 8)
-
-
-def rdb_scratch(n, h, w, device):
-    return torch.empty((L.load().mt_rdb_scratch_floats(n, h, w),), device=device, dtype=torch.float32)
-
-
-def rdb_forward(weights, biases, buf, nxt, x_amax, y_amax_buf, y_amax_next, scratch, nf=64, gc=32):
-    """One ResidualDenseBlock5C forward (model_chn.py:588-623) as one launch: ``buf`` (n,h,w,192) holds the block
-    input in its first 64 channels and receives y1 .. y4, ``nxt[..., :64]`` receives 0.2 * conv5 + x.  ``x_amax``:
-    device scalar >= max|input|; ``y_amax_buf`` is raised by what the growth convs write, ``y_amax_next`` by conv5."""
-    cw = nf + 4 * gc
-    n, h, w_ = buf.shape[:3]
-    prec = eff_precision(True)
-    arr = (L.Conv * 5)()
-    keep = []
-    for i in range(5):
-        cin, cout = nf + i * gc, (gc if i < 4 else nf)
-        sp = LayerSpec('c', cin, cout, 3, 1, L.ACT_LRELU if i < 4 else L.ACT_NONE)
-        xin = buf[..., :cin]
-        out = buf[..., cin: cin + gc] if i < 4 else nxt[..., :nf]
-        d = L.Conv()
-        d.x, d.y = view_of(xin), view_of(out)
-        keep.append(_fill_forward_desc(d, sp, d.x, weights[i], biases[i], out, buf[..., :nf] if i == 4 else None,
-                                       0.2 if i == 4 else 1.0, 1.0 if i == 4 else 0.0, x_amax,
-                                       y_amax_next if i == 4 else y_amax_buf, True, prec, False))
-        C.memmove(C.byref(arr, i * C.sizeof(L.Conv)), C.byref(d), C.sizeof(L.Conv))
-    flops = 2.0 * n * h * w_ * 9 * (sum((nf + i * gc) * gc for i in range(4)) + cw * nf)
-    with _Prof('rdb_fwd_kernel', flops):
-        rc = L.load().mt_rdb_fwd(arr, L.ptr(scratch), scratch.numel(), L.ptr(y_amax_buf), L.stream_ptr())
-    if rc < 0:
-        raise L.MT355Error(f'mt_rdb_fwd failed ({rc}): {L.load().mt_last_error().decode()}')
-    return rc == 1
-
-
 def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.0, x_amax=None, y_amax=None):
     """Run one layer forward.  xv: mt_view of the input; x_shape (N,H,W).
     ``x_amax``: device scalar >= max|x| (defaults to amax_of the view's tensor;

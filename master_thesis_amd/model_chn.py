@@ -122,18 +122,23 @@ class RRDBNetFn(torch.autograd.Function):
     # and lives until after the join; every weight pack is touched (made, on first use) before the fork; each chain
     # keeps its own running max|.| scalars, merged after the join for the launches that see the whole batch.
     CHAINS = int(os.environ.get('MT355_RRDB_CHAINS', '2'))
+    CHAIN_MIN_TILES = 512
     _side = {}
 
     @staticmethod
     def _two_chains(n, t):
+        """Chains pay where a launch over 1 / CHAINS of the batch still fills the chip (>= CHAIN_MIN_TILES 8 x 16 tiles:
+        cfg 3 has 512 per half, cfg 5 1536); on small batches they only double the launch count -- RRDBNet forward, eager,
+        16 images at 256^2: 15.7 ms in two chains, 7.3 ms for ONE image in one chain (scratch/r3_rdb_test.py)."""
         c = RRDBNetFn.CHAINS
+        h, w = t.shape[1], t.shape[2]
         return (c >= 2 and n % c == 0 and n >= c and t.is_cuda and E.USE_HALO and E.PRECISION != 'f32'
-                and E.PROFILE is None)
+                and E.PROFILE is None and (n // c) * ((h + 7) // 8) * ((w + 15) // 16) >= RRDBNetFn.CHAIN_MIN_TILES)
 
     @staticmethod
-    def _chain_streams(device):
+    def _chain_streams(device, c=None):
         """(streams, image slices factory): chain 0 runs on the current stream, the others on side streams."""
-        c = RRDBNetFn.CHAINS
+        c = RRDBNetFn.CHAINS if c is None else c
         st = RRDBNetFn._side.setdefault(device, [])
         while len(st) < c - 1:
             st.append(torch.cuda.Stream(device=device))
@@ -154,23 +159,19 @@ class RRDBNetFn(torch.autograd.Function):
             streams[0].wait_event(ev)
 
     @staticmethod
-    def _trunk_forward_chains(f0, P, nf, gc, nb, conv, f16, keep):
-        """The nb x 3 dense blocks (model_chn.py:558-623) on the two halves of the batch at once."""
+    def _trunk_forward_chains(f0, P, nf, gc, nb, conv, f16, keep, nchains=None):
+        """The nb x 3 dense blocks (model_chn.py:558-623) on ``nchains`` slices of the batch at once."""
         n, h, w, _ = f0.shape
         cw = nf + 4 * gc
         dev = f0.device
-        streams = RRDBNetFn._chain_streams(dev)
+        streams = RRDBNetFn._chain_streams(dev, nchains)
         nc = len(streams)
         nbuf = 3 * nb + 1
         # every buffer up front (main stream); without a backward to feed, four rotate (an RRDB's input is read
         # again by the residual after its third block)
         pool = [torch.empty((n, h, w, cw), device=dev, dtype=torch.float32) for _ in range(nbuf if keep else 4)]
         halves = [slice(c * (n // nc), (c + 1) * (n // nc)) for c in range(nc)]
-        # one launch per dense block (mt_rdb_fwd) where its geometry fits: the kernel keeps the input's max|.| (slot i) apart
-        # from the running maximum of what it writes into the buffer (slot nbuf + i)
-        fused = E.rdb_fused_eligible(n // nc, h, w, nf, gc)
-        amax = [torch.zeros((2 * nbuf if fused else nbuf,), device=dev, dtype=torch.float32) for _ in range(nc)] if f16 else [None] * nc
-        scratch = [E.rdb_scratch(n // nc, h, w, dev) for _ in range(nc)] if fused else None
+        amax = [torch.zeros((nbuf,), device=dev, dtype=torch.float32) for _ in range(nc)] if f16 else [None] * nc
         # touch every weight pack on the main stream (first use makes it: the chains must only ever read them)
         prec = E.eff_precision(True)
         for k in range(nb):
@@ -187,12 +188,6 @@ class RRDBNetFn(torch.autograd.Function):
             sl = halves[c]
             buf, nxt = pool[idx % len(pool)][sl], pool[(idx + 1) % len(pool)][sl]
             key = f'rrdb_trunk.{k}.rdb{j}.'
-            if fused:
-                done = E.rdb_forward([P[f'{key}conv{i}.weight'] for i in range(1, 6)], [P[f'{key}conv{i}.bias'] for i in range(1, 6)],
-                                     buf, nxt, a_(c, idx), amax[c][nbuf + idx: nbuf + idx + 1] if f16 else None, a_(c, idx + 1),
-                                     scratch[c], nf, gc)
-                assert done, 'mt_rdb_fwd refused a geometry engine.rdb_fused_eligible accepted'
-                return
             for i in range(1, 5):
                 conv(f'{key}conv{i}', buf[..., :nf + (i - 1) * gc], nf + (i - 1) * gc, gc, act=LRELU,
                      out=buf[..., nf + (i - 1) * gc: nf + i * gc], x_amax=a_(c, idx), y_amax=a_(c, idx))
@@ -219,8 +214,6 @@ class RRDBNetFn(torch.autograd.Function):
                         E.absmax_into(cur, a_(c, idx))
         RRDBNetFn._join(streams)
         merged = torch.stack(amax).amax(0) if f16 else None
-        if f16 and fused:                  # whole buffer: max(input, what the block wrote into it)
-            merged = torch.maximum(merged[:nbuf], merged[nbuf:])
         bufs = [(pool[i], merged[i:i + 1] if f16 else None) for i in range(nbuf - 1)] if keep else [None]
         last = pool[(nbuf - 1) % len(pool)]
         return last, (merged[nbuf - 1: nbuf] if f16 else None), bufs

@@ -1,3 +1,6 @@
+// (round 3: built, correct -- bit-identical to the layer-by-layer launches on every size tried -- and rejected: see
+// scratch/lab/rejected/README.md.  It was exported as mt_rdb_fwd / mt_rdb_scratch_floats for one evening; the host side lived in
+// engine.rdb_forward / model_chn.RRDBNetFn._trunk_forward_chains (git history: "Fused dense-block forward kernel").)
 // One ResidualDenseBlock5C forward (model_chn.py:588-623: four growth convs 64+32(i-1) -> 32 with LeakyReLU, then
 // conv5 192 -> 64 with out = 0.2 conv5 + x) as ONE launch (round 3; SURVEY 8b `rdb_block_fwd`).
 //
