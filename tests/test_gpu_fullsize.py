@@ -150,8 +150,15 @@ def test_gradients_at_benchmark_geometry(kind):
     gbatch = _slice_batch(make_batch(8, 5, 256, 256, DEV, seed=1234), 2)
     opt = model.configure_optimizers()['optimizer']
     opt.zero_grad()
-    loss = model.training_step(gbatch, 0)
-    loss.backward()
+    # the RRDB trunk as two launch chains, as at the full batch (two clips alone would stay below the size from which
+    # chains are used: model_chn.RRDBNetFn.CHAIN_MIN_TILES)
+    from master_thesis_amd.model_chn import RRDBNetFn
+    old_min, RRDBNetFn.CHAIN_MIN_TILES = RRDBNetFn.CHAIN_MIN_TILES, 0
+    try:
+        loss = model.training_step(gbatch, 0)
+        loss.backward()
+    finally:
+        RRDBNetFn.CHAIN_MIN_TILES = old_min
     torch.cuda.synchronize()
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     if kind == 'dfpn':

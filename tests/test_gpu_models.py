@@ -200,6 +200,31 @@ def test_chn_step_multi_reference_vs_oracle(mt, chn_sd):
     np.testing.assert_allclose(float(loss), float(ref_loss), rtol=1e-4)
 
 
+def test_chn_launch_chains_equal_single_chain(mt, chn_sd):
+    """The RRDB trunk as two launch chains over the halves of the batch (model_chn.RRDBNetFn._trunk_*_chains) against
+    the single chain: same loss, same flat gradient (each chain keeps its own power-of-two scales: exact)."""
+    from master_thesis_amd.model_chn import RRDBNetFn
+    batch = to_dev(S.synthetic_batch(2, 2, 64, 64, seed=14))
+    res = []
+    old = RRDBNetFn.CHAIN_MIN_TILES
+    try:
+        for min_tiles in (10 ** 9, 0):
+            RRDBNetFn.CHAIN_MIN_TILES = min_tiles
+            vgg = mt.VGGFeatures(device=DEV)
+            model = mt.CHN(vgg, None, mt.DFPN(vgg, **KW), **KW)
+            model.load_state_dict(chn_sd)
+            model = model.to(DEV)
+            opt = model.configure_optimizers()['optimizer']
+            opt.zero_grad()
+            loss = model.training_step(batch, 0)
+            loss.backward()
+            res.append((float(loss), opt.flat_g.clone()))
+    finally:
+        RRDBNetFn.CHAIN_MIN_TILES = old
+    np.testing.assert_allclose(res[1][0], res[0][0], rtol=1e-6)
+    assert float((res[1][1] - res[0][1]).norm() / res[0][1].norm()) < 1e-5
+
+
 def test_optimizer_step_moves_loss(mt, dfpn_sd):
     """End-to-end: two DFPN optimizer steps through configure_optimizers()."""
     model = mt.DFPN(mt.VGGFeatures(device=DEV), **KW)
