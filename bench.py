@@ -188,6 +188,18 @@ def warp_roofline(pairs=1024, size=256):
             'bytes_per_launch': bytes_}
 
 
+def csrc_sha16():
+    """Hash of the kernel sources (names + contents, sorted): tools/collect_profiles.sh stamps the PMC summaries with it."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'master_thesis_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h', '.cpp')):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(label):
     """HBM bytes per launch of the kernel ``label`` from the newest committed rocprofv3 PMC passes
     (profiles/rNN_pmc_hbm_traffic.txt: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 correction
@@ -207,14 +219,14 @@ def pmc_traffic(label):
             f = rest.strip(',').split(',')
             out = {'traffic': float(f[3]) * 1e6, 'traffic_unit': 'bytes/launch (PMC, (2*FETCH_SIZE+WRITE_SIZE)*1024)',
                    'traffic_source': os.path.relpath(files[-1], ROOT), 'traffic_launches': int(f[0])}
-            # a counter file older than the kernels it describes goes stale silently: say so
-            srcs = glob.glob(os.path.join(ROOT, 'master_thesis_amd', 'csrc', '*.hip')) + \
-                glob.glob(os.path.join(ROOT, 'master_thesis_amd', 'csrc', '*.h'))
-            newest = max(srcs, key=os.path.getmtime) if srcs else None
-            if newest and os.path.getmtime(newest) > os.path.getmtime(files[-1]):
+            # a counter file that describes an earlier build of the kernels goes stale silently: the collection script
+            # stamps it with a hash of the kernel sources (file times do not survive a checkout), compare
+            stamp = [r.split()[-1] for r in rows if r.startswith('# csrc_sha16:')]
+            if not stamp or stamp[0] != csrc_sha16():
                 out['traffic_stale'] = True
-                print(f'bench.py: WARNING {out["traffic_source"]} is older than {os.path.relpath(newest, ROOT)}: roofline.traffic '
-                      'describes an earlier build of the kernels (re-run tools/collect_profiles.sh)', file=sys.stderr)
+                print(f'bench.py: WARNING {out["traffic_source"]} was collected on other kernel sources (stamp '
+                      f'{stamp[0] if stamp else "none"}, now {csrc_sha16()}): roofline.traffic describes an earlier build '
+                      '(re-run tools/collect_profiles.sh)', file=sys.stderr)
             return out
     return none
 

@@ -21,7 +21,8 @@ done
 # matrix-pipe utilisation: MFMA busy cycles (summed over the 1024 SIMDs) against the GPU-active cycles
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $out/pmc_MFMA -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-check $only --no-graph > $out/pmc_MFMA.json 2> $out/pmc_MFMA.err || echo "pmc MFMA failed"
 python3 - "$out" "$tag" "$sfx" "$only" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, sys, collections, os
+sys.path.insert(0, os.getcwd())
 out, tag, sfx, only = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 what = 'CHN cfg3 step' if sfx else 'DFPN cfg2 step'
 def load(counter):
@@ -47,6 +48,8 @@ with open(f'{out}/{tag}_pmc{sfx}_hbm_traffic.txt', 'w') as o:
     o.write('# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace), bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-check ' + only + ' --no-graph\n')
     o.write(f'# ({what}s, eager launches, + the 2048-pair correlation micro-benchmark).  Units: KB per dispatch; gfx950 correction\n')
     o.write('# (MI355X_MICROARCH.md, HBM): FETCH_SIZE reads 1/2 of a wide coalesced stream -> bytes = (2*FETCH + WRITE) * 1024\n')
+    import bench
+    o.write('# csrc_sha16: ' + bench.csrc_sha16() + '\n')
     o.write('kernel,launches,avg_FETCH_SIZE_KB,avg_WRITE_SIZE_KB,corrected_MB_per_launch,avg_ms_under_pmc,corrected_GB_per_s\n')
     for _, k, n, f, w, mb, ms in rows[:40]:
         name = k.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '').split('(')[0]
