@@ -172,10 +172,13 @@ class _Prof:
             PROFILE.append((self.name, self.flops, self.e0, self.e1))
 
 
-def bump_weight_epoch():
+def bump_weight_epoch(changed=None):
     """The parameters changed (optimizer step, new model): per-epoch caches are
     dropped, packs that were used during the epoch that ends are refreshed in one
-    batch (repack_all), the others are forgotten."""
+    batch (repack_all), the others are forgotten.  ``changed`` = (lo, hi) byte range
+    of the memory that was rewritten (FlatAdam: its flat parameter buffer): packs of
+    weights outside it -- the frozen VGG, the aligner inside a CHN step: two thirds of
+    the packs there -- are left alone."""
     global WEIGHT_EPOCH
     ended = WEIGHT_EPOCH
     WEIGHT_EPOCH += 1
@@ -187,7 +190,7 @@ def bump_weight_epoch():
     live = {e.wa.data_ptr() for e in _packs.values() if e.wa is not None}
     for k in [k for k, e in _wamax.items() if e.out.data_ptr() not in live]:
         del _wamax[k]                    # scale scalars live as long as a pack reads them
-    repack_all()
+    repack_all(changed)
 
 
 def cpad(c):
@@ -445,21 +448,26 @@ def drop_epoch_cache():
 def pack_state():
     """Everything a captured graph's pack launches point at (entries, tables, scale
     chunks): a graph keeps this alive for as long as it may be replayed."""
-    return (list(_packs.values()), list(_wamax.values()), dict(_tables),
+    tables = {k: (dict(v) if isinstance(v, dict) else v) for k, v in _tables.items()}      # (snapshots: the live dicts get cleared)
+    return (list(_packs.values()), list(_wamax.values()), tables,
             [c for chunks in _wamax_chunks.values() for c in chunks[0]])
 
 
-def repack_all():
-    """Refresh every registered pack from the current parameters: zero the weight
-    scale scalars, one mt_absmax_segments launch, one mt_weight_pack_jobs launch."""
-    ents = list(_packs.values())
+def _touched(weights, changed):
+    return changed is None or any(changed[0] <= w.data_ptr() < changed[1] for w in weights)
+
+
+def repack_all(changed=None):
+    """Refresh the registered packs from the current parameters: zero their weight scale scalars,
+    one mt_absmax_segments launch, one mt_weight_pack_jobs launch.  ``changed`` (see
+    bump_weight_epoch): only packs with a source weight inside that byte range."""
+    ents = [e for e in _packs.values() if _touched(e.keep, changed)]
     if not ents:
         return
+    amaxes = [e for e in _wamax.values() if _touched(e.weights, changed)]
     if not REPACK_BATCHED:
-        for chunks in _wamax_chunks.values():
-            for c in chunks[0]:
-                c.zero_()
-        for e in _wamax.values():
+        for e in amaxes:
+            e.out.zero_()
             for w in e.weights:
                 L.call('mt_absmax_flat', L.ptr(w), w.numel(), L.ptr(e.out), L.stream_ptr())
         for e in ents:
@@ -467,28 +475,44 @@ def repack_all():
                 _run_job(j)
         return
     # (buffer addresses are part of the signature: an entry that was dropped and re-made has the same key)
-    sig = (tuple((k, e.out.data_ptr()) for k, e in _packs.items()), tuple((k, e.out.data_ptr()) for k, e in _wamax.items()))
-    if _tables.get('sig') != sig:
+    sig = (tuple((k, e.out.data_ptr()) for k, e in _packs.items()), tuple((k, e.out.data_ptr()) for k, e in _wamax.items()), changed)
+    tab = _tables.setdefault('by_range', {})
+    if _tables.get('sig') != sig[:2]:
+        tab.clear()                       # the set of packs changed: every cached table is stale
+        _tables['sig'] = sig[:2]
+    cur = tab.get(changed)
+    if cur is None:
         assert not torch.cuda.is_current_stream_capturing(), \
             'the set of weight packs changed inside a graph capture (run the step eagerly first)'
         dev = ents[0].out.device
         jobs = [j for e in ents for j in e.jobs]
-        segs = [L.AmaxSeg(w.data_ptr(), w.numel(), e.out.data_ptr()) for e in _wamax.values() for w in e.weights]
+        segs = [L.AmaxSeg(w.data_ptr(), w.numel(), e.out.data_ptr()) for e in amaxes for w in e.weights]
 
         def table(items, ctype):
             host = (ctype * len(items))(*items)
             t = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(dev)
             return t, host, len(items)
-        _tables['jobs'] = table(jobs, L.PackJob)
-        _tables['segs'] = table(segs, L.AmaxSeg) if segs else None
-        _tables['sig'] = sig
-    if _tables['segs'] is not None:
+        # the scale scalars to reset: positions inside the zero-filled chunks they were handed out from
+        zero = []
         for chunks in _wamax_chunks.values():
             for c in chunks[0]:
+                idx = [(e.out.data_ptr() - c.data_ptr()) // 4 for e in amaxes
+                       if c.data_ptr() <= e.out.data_ptr() < c.data_ptr() + 4 * c.numel()]
+                if len(idx) == c.numel() or (changed is None and idx):
+                    zero.append((c, None))
+                elif idx:
+                    zero.append((c, torch.tensor(idx, device=c.device, dtype=torch.long)))
+        cur = tab[changed] = dict(jobs=table(jobs, L.PackJob), segs=table(segs, L.AmaxSeg) if segs else None, zero=zero)
+        _tables['jobs'], _tables['segs'] = cur['jobs'], cur['segs']      # (kept alive with the graph: pack_state)
+    if cur['segs'] is not None:
+        for c, idx in cur['zero']:
+            if idx is None:
                 c.zero_()
-        t, host, n = _tables['segs']
+            else:
+                c.index_fill_(0, idx, 0.0)
+        t, host, n = cur['segs']
         L.call('mt_absmax_segments', L.ptr(t), n, L.stream_ptr())
-    t, host, n = _tables['jobs']
+    t, host, n = cur['jobs']
     L.call('mt_weight_pack_jobs', L.ptr(t), C.cast(host, C.c_void_p), n, L.stream_ptr())
 
 

@@ -104,7 +104,8 @@ class FlatAdam(torch.optim.Optimizer):
             L.call('mt_adam_step', L.ptr(self.flat_p), L.ptr(self.flat_g), L.ptr(self.exp_avg),
                    L.ptr(self.exp_avg_sq), self.flat_p.numel(), b1, b2, g['lr'] / bc1, 1.0 / math.sqrt(bc2), g['eps'],
                    self.grad_scale, L.stream_ptr())
-        E.bump_weight_epoch()
+        # only this buffer was rewritten: packs of weights outside it (frozen VGG / aligner) stay as they are
+        E.bump_weight_epoch((self.flat_p.data_ptr(), self.flat_p.data_ptr() + 4 * self.flat_p.numel()))
         return loss
 
     def sync_device_lr(self):
