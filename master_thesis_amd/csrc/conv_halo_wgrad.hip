@@ -240,20 +240,28 @@ struct WgBatch {
   const float* damax[MT_WGRAD_BATCH_MAX]; const float* gamax[MT_WGRAD_BATCH_MAX];
 };
 struct WgOne {};
+// Rows of a pixel tile of wgrad_pc_kernel.  8-row tiles (possible with one term of D: no D_lo plane, and 72-element LDS
+// rows) pay on SMALL images only: on the 16 x 16 images of SeparableConv4d the G patch of a tile shrinks from 1.5x to
+// 1.25x its pixels (5.40 -> 5.03 ms for 256 -> 256 on 8192 images), on 128^2 / 256^2 images the doubled staging registers
+// spill and the 72-element rows cost bank conflicts (1.37 -> 1.43 ms).  engine.py mirrors this rule.
+inline int wgpc_tr(int d_terms, int KS, int Hd) { return (d_terms == 1 && KS == 3 && Hd <= 16 && (Hd & 7) == 0) ? 8 : 4; }
 
 // DT = 1 (mt_wgrad.d_terms): D enters with its LEADING 16-bit term only -- two partial products (D_hi G_hi, D_hi G_lo)
 // instead of three, no D_lo plane staged or read.  D then carries 11 (fp16) significant bits: rounding errors that are
 // independent from pixel to pixel, so a gradient summed over ~10^5 .. 10^6 pixels is off by ~1e-4 relative.
-template <int KS, int KHB, int FMT, bool BATCH = false, int DT = 2>
+template <int KS, int KHB, int FMT, bool BATCH = false, int DT = 2, int TRP = 4>
 __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, int tiles_x, int tiles_per_split, int ntiles,
                                                          int with_bias, int kh_base,
                                                          std::conditional_t<BATCH, WgBatch, WgOne> tab) {
-  constexpr int NS = 2, TR = 4, TW = 16, PX = TR * TW, CH = 64, LD = CH + MT_WGPC_PAD;
+  // pixel tile: 4 x 16; with one term of D (no D_lo plane) and 72-element rows two 8 x 16 images fit as well (wgpc_tr)
+  constexpr int NS = 2, TR = TRP, TW = 16, PX = TR * TW, CH = 64, LD = CH + (TR == 8 ? 8 : MT_WGPC_PAD);
+  static_assert(TR == 4 || (TR == 8 && DT == 1), "8-row tiles need the one-term form");
   constexpr int GH = TR - 1 + KHB, GW = TW - 1 + KS, GP = GH * GW;
   constexpr int ND4 = PX * (CH / 4), RD = ND4 / 256;
   constexpr int NG4 = GP * (CH / 4), RG = (NG4 + 255) / 256;
   constexpr int NT = KHB * KS;
-  constexpr int D_E = NS * PX * LD, G_E = NS * GP * LD, BUF_E = D_E + G_E;
+  constexpr int D_E = DT * PX * LD, G_E = NS * GP * LD, BUF_E = D_E + G_E;
+  static_assert(2 * BUF_E * 2 <= 160 * 1024, "two images must fit the LDS");
   __shared__ __attribute__((aligned(16))) __bf16 sm[2 * BUF_E];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -716,7 +724,10 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   const bool pc = d->stride == 1 && prec != MT_PREC_BF16X6 && wgrad_pc() && (d->KH == 3 || pc5);
   // 3x3 stride 1 (two-term splits): 8-row pixel tiles (measured: +6 %; the 5x5 gradient loses 3 % with them) (twice the MFMAs per staged tile and barrier)
   const bool tall = !pc && d->stride == 1 && d->KH == 3 && prec != MT_PREC_BF16X6 && wgrad3_tall();
-  const int trows = tall ? 8 : 4;
+  // 16 gathered channels (and no up-sampled gather): four taps share a B tile (MT355_WGRAD_THIN=0: the kernel below)
+  static const bool thin_on = [] { const char* e = getenv("MT355_WGRAD_THIN"); return !(e && e[0] == '0'); }();
+  const bool thin = pc && thin_on && d->g.C == 16 && d->ups == 0 && !d->skip_tiles;
+  const int trows = tall ? 8 : ((pc && !thin && prec == MT_PREC_F16X3) ? wgpc_tr(d->d_terms, d->KH, k.Hd) : 4);
   const int tiles_y = (k.Hd + trows - 1) / trows, tiles_x = (k.Wd + 15) / 16;
   const int ntiles = d->d.N * tiles_y * tiles_x;
   const int tps = (ntiles + d->splits - 1) / d->splits;
@@ -729,9 +740,7 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
 #define MT_WGPC(KS, KHB, FMT, KH_BASE) \
   do { if (d->d_terms == 1) hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT, false, 1>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); \
        else hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); } while (0)
-  // 16 gathered channels (and no up-sampled gather): four taps share a B tile (MT355_WGRAD_THIN=0: the kernel below)
-  static const bool thin_on = [] { const char* e = getenv("MT355_WGRAD_THIN"); return !(e && e[0] == '0'); }();
-  if (pc && thin_on && d->g.C == 16 && d->ups == 0 && !d->skip_tiles) {
+  if (thin) {
     const dim3 grid(k.atiles, d->splits);
     if (d->KH == 3) {
       if (prec == MT_PREC_F16X3) hipLaunchKernelGGL((wgrad_thin_kernel<3, 1>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
@@ -744,7 +753,9 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   }
   if (pc) {
     const bool f16 = prec == MT_PREC_F16X3;
-    if (d->KH == 3) { if (f16) MT_WGPC(3, 3, 1, 0); else MT_WGPC(3, 3, 0, 0); }
+    if (d->KH == 3 && f16 && trows == 8)
+      hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, false, 1, 8>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, WgOne{});
+    else if (d->KH == 3) { if (f16) MT_WGPC(3, 3, 1, 0); else MT_WGPC(3, 3, 0, 0); }
     // 5 x 5: kernel rows {0,1} | {2,3} | {4} (15 accumulator tiles would not leave the MFMA waves
     // their operand registers at two waves per SIMD; the staging is off the critical path here)
     else if (f16) { MT_WGPC(5, 2, 1, 0); MT_WGPC(5, 2, 1, 2); MT_WGPC(5, 1, 1, 4); }
@@ -824,12 +835,15 @@ extern "C" int mt_wgrad_run_batch(const mt_wgrad* descs, int32_t n, void* stream
   k.M = d->d.N * d->d.H * d->d.W; k.per_split = 0;
   k.atiles = (k.Cd + 63) / 64; k.btiles = (k.Cg + 63) / 64;
   k.slabs = d->slabs; k.damax = d->d_amax; k.gamax = d->g_amax; k.skip = d->skip_tiles;
-  const int tiles_y = (k.Hd + 3) / 4, tiles_x = (k.Wd + 15) / 16;
+  const int trb = prec == MT_PREC_F16X3 ? wgpc_tr(d->d_terms, 3, k.Hd) : 4;
+  const int tiles_y = (k.Hd + trb - 1) / trb, tiles_x = (k.Wd + 15) / 16;
   const int ntiles = d->d.N * tiles_y * tiles_x;
   const int tps = (ntiles + d->splits - 1) / d->splits;
   const dim3 grid(k.atiles * k.btiles, d->splits, n);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (prec == MT_PREC_F16X3 && d->d_terms == 1)
+  if (prec == MT_PREC_F16X3 && d->d_terms == 1 && trb == 8)
+    hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, true, 1, 8>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
+  else if (prec == MT_PREC_F16X3 && d->d_terms == 1)
     hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, true, 1>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
   else if (prec == MT_PREC_F16X3)
     hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, true>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);

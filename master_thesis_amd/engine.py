@@ -852,6 +852,9 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
         # pixel tiles of 8 x 16 for the single-role 3x3 stride-1 gradient, 4 x 16 otherwise (as mt_wgrad_halo_try_launch)
         trows = 8 if (not pc and spec.k == 3 and spec.stride == 1 and prec != 'bf16x6'
                       and os.environ.get('MT355_WGRAD3_TALL', '1') != '0') else 4
+        if (pc and WGRAD_D_TERMS == 1 and prec == 'f16x3' and spec.k == 3 and dv.H <= 16 and dv.H % 8 == 0
+                and not (bp == 16 and d.ups == 0 and sub_blocks is None and os.environ.get('MT355_WGRAD_THIN', '1') != '0')):
+            trows = 8          # mirrors wgpc_tr() in conv_halo_wgrad.hip: 8-row tiles on small images (one term of D)
         ntiles = dv.N * ((dv.H + trows - 1) // trows) * ((dv.W + 15) // 16)
         want = WGRAD_PC_BLOCKS if pc else 512        # blocks in flight: one 512-thread block per CU for pc
         # (fp16 terms only: the leading bf16 term has 8 bits -- 1.3e-3 on a noise gradient; the stride-2 gathers of the
