@@ -3,6 +3,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include "mt355.h"
+#include "common.h"
+#include <mutex>
+#include <unordered_map>
 
 static thread_local char g_err[512] = "";
 
@@ -24,3 +27,33 @@ int mt_check_launch(const char* what) {
 
 extern "C" int mt_version(void) { return 1; }
 extern "C" const char* mt_last_error(void) { return g_err; }
+
+// Per-stream scratch of the two-level amax reduction (common.h: AmaxScratch).  A pool of 64 zero-filled areas is
+// allocated by the first call that is not inside a graph capture (allocation and memset are not capturable); a stream
+// keeps the area it is given.  nullptr (callers fall back to raise_amax) while there is no pool or when it is used up.
+AmaxScratch* mt_amax_scratch(hipStream_t s) {
+  constexpr int POOL = 64;
+  static std::mutex mu;
+  static std::unordered_map<hipStream_t, AmaxScratch*> map;
+  static AmaxScratch* pool = nullptr;
+  static int used = 0;
+  static bool failed = false;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = map.find(s);
+  if (it != map.end()) return it->second;
+  if (!pool && !failed) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return nullptr;                       // (not remembered: the stream gets an area once the pool exists)
+    }
+    if (hipMalloc(&pool, sizeof(AmaxScratch) * POOL) != hipSuccess || hipMemset(pool, 0, sizeof(AmaxScratch) * POOL) != hipSuccess) {
+      (void)hipGetLastError();
+      pool = nullptr;
+      failed = true;
+    }
+  }
+  AmaxScratch* p = (pool && used < POOL) ? pool + used++ : nullptr;
+  map[s] = p;
+  return p;
+}

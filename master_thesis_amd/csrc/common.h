@@ -27,6 +27,11 @@ static inline bool mt_view_ok(const mt_view* v) {
 // entry points that do not implement the two-level image index
 static inline bool mt_view_flat(const mt_view* v) { return mt_view_ok(v) && v->n_in >= v->N; }
 
+// Scratch of the two-level max reduction of a launch (conv_common.h: raise_amax_block): 64 slots, 256 bytes apart.
+// One per stream (launches of a stream do not overlap), zero-filled at creation; every launch leaves it zero-filled.
+struct AmaxScratch { unsigned max[64 * 64]; unsigned cnt[64 * 64]; unsigned cnt2[64]; };
+AmaxScratch* mt_amax_scratch(hipStream_t s);      // api.cpp; nullptr on allocation failure (callers then use raise_amax)
+
 static inline int mt_grid_1d(int64_t work, int block, int cap = 4096) {
   int64_t g = (work + block - 1) / block;
   if (g < 1) g = 1;
@@ -46,6 +51,50 @@ __device__ __forceinline__ float mt_dact_fn(float s, int act) {
   if (act == MT_ACT_RELU) return s > 0.f ? 1.f : 0.f;
   if (act == MT_ACT_LRELU02) return s > 0.f ? 1.f : 0.2f;
   return 1.f;
+}
+
+// max|y| of a launch in two levels.  Why: atomics on ONE address are served one at a time at the memory side -- about
+// 11 ns each on this part (scratch/lab/store_path.hip: 4096 of them add 45 us to an 8 us launch, and every load or
+// store of the launch that maps to the same memory channel queues behind them) -- and with a thousand blocks in
+// lock-step the filter read of raise_amax() is stale for all of them.  Here a block reduces its waves through LDS and
+// raises ONE of 64 slots (256 bytes apart, slot = block & 63); the block that completes a slot's count counts the slot,
+// and the block that completes the slots folds them into *dst with one atomic and leaves the scratch zero-filled.
+// Order without a fence (a device-scope release would write the L2 back): the atomics are performed at the memory
+// side, each one is a RETURNING atomic whose result feeds the next one's operand.
+// Every block of the launch must call it, with all its threads; ``red`` = 16 floats of LDS nobody reads any more.
+__device__ __forceinline__ void raise_amax_block(float* dst, AmaxScratch* scr, float v, float* red, unsigned bid,
+                                                 unsigned nblocks) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (wave != 0) return;
+  float m = lane < nw ? red[lane] : 0.f;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  const unsigned nslots = nblocks < 64u ? nblocks : 64u;
+  unsigned fin = 0;
+  if (lane == 0) {
+    const unsigned slot = bid & 63u, members = (nblocks >> 6) + (slot < (nblocks & 63u) ? 1u : 0u);
+    const unsigned was = atomicMax(&scr->max[slot * 64], __float_as_uint(m));
+    const unsigned old = atomicAdd(&scr->cnt[slot * 64], 1u + (was >> 31));          // (was: a non-negative float, bit 31 = 0)
+    if (old + 1 == members) {
+      const unsigned z = atomicExch(&scr->cnt[slot * 64], 0u);
+      fin = atomicAdd(&scr->cnt2[0], 1u + (z >> 31)) + 1 == nslots;
+    }
+  }
+  fin = __shfl(fin, 0, 64);
+  if (fin) {
+    float mm = lane < (int)nslots ? __uint_as_float(atomicExch(&scr->max[lane * 64], 0u)) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+    if (lane == 0) {
+      const unsigned z = atomicExch(&scr->cnt2[0], 0u);
+      if (mm > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(mm) + (z >> 31));
+    }
+  }
 }
 
 __device__ __forceinline__ float mt_wave_sum(float v) {

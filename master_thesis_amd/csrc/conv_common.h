@@ -23,6 +23,7 @@ struct ConvK {
   int par;                         // 1: stride-2 transposed gather decomposed into 4 parity classes (blockIdx.z)
   const float* xamax; const float* wamax;   // F16X3: device scalars max|X|, max|W| (power-of-two scaling)
   float* yamax;                              // optional: raised to max|y| over the values this launch writes
+  AmaxScratch* ascr;                         // kernels that reduce max|y| in two levels (raise_amax_block): the stream's scratch
 };
 
 // Raise the device scalar *dst to at least v (v >= 0; non-negative floats order like their
@@ -204,6 +205,93 @@ __device__ __forceinline__ float halo_epilogue_lean(const ConvK& p, int n, int o
   return vmax;
 }
 
+// The same epilogue in TWO phases, for kernels that finish several tiles per lane: every optional operand of every
+// tile is requested (halo_epi_load) before the first store of any tile (halo_epi_store), and the bias value comes
+// from the caller, loaded before the main loop.  Why: on this ISA loads and stores share one counter (vmcnt), so
+// a load issued after a store waits for the store's acknowledgement from L2 -- a bias / residual load per tile
+// after the previous tile's stores costs 2 us or more per tile when every block of the launch writes at once
+// (measured with wall-clock stamps, DESIGN.md "Epilogue stalls").
+template <int NE>
+struct EpiOps { float r[NE], y[NE], d[NE]; };
+
+template <int NE, class PixFn>
+__device__ __forceinline__ unsigned halo_epi_load(const ConvK& p, int n, int o, PixFn pix, EpiOps<NE>& t) {
+  static_assert(NE <= 32, "one mask word");
+  unsigned okm = 0;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    int oy, ox;
+    pix(e, oy, ox);
+    if (o < p.Co && oy < p.Ho && ox < p.Wo) okm |= 1u << e;
+  }
+  if (p.res) {
+    const float* rb = p.res + ((long)n * p.rsn + o);
+    const int rsh = (int)p.rsh, rsw = (int)p.rsw;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      int oy, ox;
+      pix(e, oy, ox);
+      t.r[e] = ((okm >> e) & 1) ? rb[oy * rsh + ox * rsw] : 0.f;
+    }
+  }
+  if (p.accumulate) {
+    const float* yb = p.y + ((long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + o);
+    const int ysh = (int)p.ysh, ysw = (int)p.ysw;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      int oy, ox;
+      pix(e, oy, ox);
+      t.y[e] = ((okm >> e) & 1) ? yb[oy * ysh + ox * ysw] : 0.f;
+    }
+  }
+  if (p.ds && o >= p.dact_c0) {
+    const float* db = p.ds + ((long)n * p.dsn + o);
+    const int dsh = (int)p.dsh, dsw = (int)p.dsw;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      int oy, ox;
+      pix(e, oy, ox);
+      t.d[e] = ((okm >> e) & 1) ? db[oy * dsh + ox * dsw] : 1.f;
+    }
+  }
+  return okm;
+}
+
+// v[e] = accumulator * 1/scale; bv = bias[o] (0 without one).  Same operation order as halo_epilogue.
+template <int NE, class PixFn>
+__device__ __forceinline__ float halo_epi_store(const ConvK& p, int n, int o, float (&v)[NE], PixFn pix, float bv,
+                                                const EpiOps<NE>& t, unsigned okm) {
+  float* yb = p.y + ((long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + o);
+  const int ysh = (int)p.ysh, ysw = (int)p.ysw;
+  const bool dact = p.ds && o >= p.dact_c0;
+  float vmax = 0.f;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    float x = mt_act_fn(v[e] + bv, p.act) * p.alpha;
+    if (p.res) x += p.beta * t.r[e];
+    if (p.accumulate) x += t.y[e];
+    if (dact) x *= mt_dact_fn(t.d[e], p.dact);
+    int oy, ox;
+    pix(e, oy, ox);
+    if ((okm >> e) & 1) {
+      yb[oy * ysh + ox * ysw] = x;
+      vmax = fmaxf(vmax, fabsf(x));
+    }
+  }
+  return vmax;
+}
+
+// max|y| of a launch: two levels through the stream's scratch (common.h: raise_amax_block) where the launch function set
+// one, else one filtered atomic per wave.  Every thread of every block of the launch must call it; ``lds`` = 64 bytes
+// of shared memory that nobody reads any more.
+__device__ __forceinline__ void finish_amax(const ConvK& p, float vmax, void* lds) {
+  if (!p.yamax) return;
+  if (p.ascr)
+    raise_amax_block(p.yamax, p.ascr, vmax, reinterpret_cast<float*>(lds), blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
+                     gridDim.x * gridDim.y * gridDim.z);
+  else raise_amax(p.yamax, vmax);
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -357,6 +445,7 @@ inline int fill_convk(const mt_conv* d, ConvK* k) {
   k->accumulate = d->accumulate;
   k->zb = 1; k->zdiv = 1; k->xz = k->wz = k->yz = 0; k->par = 0; k->Kp = 0;
   k->xamax = d->x_amax; k->wamax = d->w_amax; k->yamax = d->y_amax;
+  k->ascr = nullptr;                 // (set by the launch functions of the kernels that use it)
   return MT_OK;
 }
 

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_kernel(ConvK p, int tiles_y
       else vmax = fmaxf(vmax, halo_epilogue<16>(p, n, n0 + wn * TN * 32 + b * 32 + li, vals, pix));
     }
   }
-  if (p.yamax) raise_amax(p.yamax, vmax);
+  finish_amax(p, vmax, sH);
 }
 
 
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_rb_kernel(ConvK p, int tile
       ox = tx0 + (i32 < 16 ? i32 : ((i32 - HW_) & 15));
     }));
   }
-  if (p.yamax) raise_amax(p.yamax, vmax);
+  finish_amax(p, vmax, sH);
 }
 
 
@@ -441,6 +441,7 @@ int mt_halo_try_launch(const mt_conv* d, void* stream) {
   if (fill_convk(d, &k) != MT_OK) return 0;
   k.Kp = ((k.K + 31) / 32) * 32;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (k.yamax) k.ascr = mt_amax_scratch(s);
   if (d->KH == 3) {
     if (prec == MT_PREC_BF16X6) launch_halo<3, 3, 0>(k, s);
     else if (prec == MT_PREC_BF16X3) launch_halo<3, 2, 0>(k, s);

@@ -62,7 +62,10 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_planes_kernel(ConvK p, Plan
   const int ubase = q.zclasses ? blockIdx.z : 0;
   const int oya = q.zclasses ? (int)(blockIdx.z >> 1) : q.oya, oxa = q.zclasses ? (int)(blockIdx.z & 1) : q.oxa;
   const int Hc = q.zclasses ? (p.Ho - oya + 1) >> 1 : q.Hc, Wc = q.zclasses ? (p.Wo - oxa + 1) >> 1 : q.Wc;
-  if (ty0 >= Hc || tx0 >= Wc) return;
+  if (ty0 >= Hc || tx0 >= Wc) {     // (an empty parity-class tile: it still takes part in the launch's max reduction)
+    finish_amax(p, 0.f, sH);
+    return;
+  }
 
   // halo staging coordinates (window origin -1): the same for every unit, only the bounds differ
   long h_off[RH];
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_planes_kernel(ConvK p, Plan
       ox = j < Wc ? j * q.omul + oxa : p.Wo;
     }));
   }
-  if (p.yamax) raise_amax(p.yamax, vmax);
+  finish_amax(p, vmax, sH);
 }
 
 __global__ void weight_pack_planes_kernel(const float* src, int A, int B, long sa, long sb, long st, __bf16* dst, int nchunk,
@@ -242,6 +245,7 @@ int mt_halo_planes_try_launch(const mt_conv* d, void* stream) {
   ConvK k;
   if (fill_convk(d, &k) != MT_OK) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (k.yamax) k.ascr = mt_amax_scratch(s);
   const int fmt = d->precision == MT_PREC_F16X3 ? 1 : 0;
   const UnitTaps t = unit_taps(d->transposed, d->KH, d->pad);
   const int nchunk = k.C / 32;

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_wino_kernel(ConvK p, int ti
       }));
     }
   }
-  if (p.yamax) raise_amax(p.yamax, vmax);
+  finish_amax(p, vmax, sV);
 }
 
 // ---- <= 64 output channels: the XI axis split over the waves (round 3) ------------------------
@@ -202,16 +202,35 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_wino_kernel(ConvK p, int ti
 // nothing is fetched twice by a block), the image is single-buffered (41 KB: three blocks per CU), two barriers per
 // 32-channel chunk.  The four xi meet in the epilogue through LDS: per M tile every wave posts its products, then
 // finishes one output row of the tile (y0 = m0 + m1 + m2, y1 = m1 - m2 - m3).
+#if MT_WINOX_TRACE            // (lab: wall-clock stamps of the stages of every block, read back by mt_lab_winox_trace)
+__device__ unsigned long long winox_trace[4096 * 16];
+#define WX_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) winox_trace[blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define WX_STAMP(i) do {} while (0)
+#endif
+#ifndef MT_WINOX_OCC1
+#define MT_WINOX_OCC1 3
+#endif
+#ifndef MT_WINOX_ABL          // (lab ablations: 1 no halo loads, 2 no transform / split / image stores, 3 no MFMAs, 4 no weight loads)
+#define MT_WINOX_ABL 0
+#endif
 template <int FMT, int TN>
-__global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK p, int tiles_y, int tiles_x) {
+__global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC1 : 2) void igemm_winox_kernel(ConvK p, int tiles_y, int tiles_x) {
   constexpr int NS = 2, CK = 32, TH = 8, TW = 16, BN = 32 * TN, TM = 2;
   constexpr int NTX = TW / 2, ROWS = TH + 2;
-  constexpr int ENT = CK, ROW_E = 4 * NTX * ENT + 8, PLANE_E = ROWS * ROW_E;
+  // TN == 1: the 16-byte slots of an entry are XOR-swizzled by the row instead of padding the rows by 16 bytes: the image
+  // is 40960 bytes exactly, FOUR blocks share the 160 KB of a CU
+  constexpr bool SWZ = TN == 1;
+  constexpr int ENT = CK, ROW_E = 4 * NTX * ENT + (SWZ ? 0 : 8), PLANE_E = ROWS * ROW_E;
   constexpr int NIT = ROWS * NTX * (CK / 4), RI = (NIT + 255) / 256;
   constexpr int KSTEPS = CK / 16;
   static_assert(4 * TN * 16 * 64 * 4 <= NS * PLANE_E * 2, "the epilogue exchange of one M tile must fit the image");
-  __shared__ __attribute__((aligned(16))) __bf16 sV[NS * PLANE_E];
+#ifndef MT_WINOX_LDS_PAD      // (lab: extra LDS elements, to measure what one block per CU fewer costs)
+#define MT_WINOX_LDS_PAD 0
+#endif
+  __shared__ __attribute__((aligned(16))) __bf16 sV[NS * PLANE_E + MT_WINOX_LDS_PAD];
 
+  WX_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -253,13 +272,24 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#if MT_WINOX_ABL == 6          // (lab: half the halo registers -- WRONG results, the cost model of the lane-exchange form)
+        if (b < 2) continue;
+#endif
+#if MT_WINOX_ABL != 1
         if (((it_ok[i] >> b) & 1u) && cin)
           v = *reinterpret_cast<const f32x4*>(xin + (it_row[i] + ((it_lx[i] + b) >> p.ups) * xsw + c0));
+#endif
         rh[i][b] = v;
+#if MT_WINOX_ABL == 6
+        rh[i][b - 2] = v;
+#endif
       }
     }
   };
   auto store_v = [&]() {
+#if MT_WINOX_ABL == 2
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
       const int q = tid + 256 * i;
@@ -267,7 +297,7 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK
         const int c4 = q & 7, t = (q >> 3) & 7, r = q >> 6;
         const f32x4 d0 = rh[i][0], d1 = rh[i][1], d2 = rh[i][2], d3 = rh[i][3];
         const f32x4 v[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
-        __bf16* dst = sV + r * ROW_E + t * ENT + 4 * c4;
+        __bf16* dst = sV + r * ROW_E + t * ENT + (SWZ ? 8 * ((c4 >> 1) ^ (r & 3)) + 4 * (c4 & 1) : 4 * c4);
 #pragma unroll
         for (int x4 = 0; x4 < 4; ++x4) {
           bf16x4 parts[NS];
@@ -301,21 +331,46 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK
   // MFMA row i of M tile a = (output row 4a + (i >> 3), column pair i & 7); this wave's xi plane of the image
   int a_base[TM];
 #pragma unroll
-  for (int a = 0; a < TM; ++a) a_base[a] = (4 * a + (li >> 3)) * ROW_E + (li & 7) * ENT + 8 * lh + xi * NTX * ENT;
+  for (int a = 0; a < TM; ++a)
+    a_base[a] = (4 * a + (li >> 3)) * ROW_E + (li & 7) * ENT + (SWZ ? 0 : 8 * lh) + xi * NTX * ENT;
 
   load_raw(0);
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) load_B(0, 0, tn, ks);
+  // what the epilogue reads that does not depend on the result: requested here, so that no load follows a store
+  float bv[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) bv[tn] = (p.bias && n0 + tn * 32 + li < p.Co) ? p.bias[n0 + tn * 32 + li] : 0.f;
+  WX_STAMP(1);
   store_v();
+  WX_STAMP(2);
   __syncthreads();
+  WX_STAMP(3);
   for (int ch = 0; ch < nchunk; ++ch) {
     const bool more = ch + 1 < nchunk;
     if (more) load_raw((ch + 1) * CK);          // in flight under the three taps
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int toff = ky * ROW_E;
+      if constexpr (TN == 1 && MT_WINOX_OCC1 >= 4) {   // four blocks per CU: 128 registers -- one k step of A fragments at a time
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          bf16x8 f1[TM][NS];
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+              f1[a][s] = *reinterpret_cast<const bf16x8*>(
+                  &sV[s * PLANE_E + a_base[a] + toff + 8 * ((lh + 2 * ks) ^ (((li >> 3) + ky) & 3))]);
+#pragma unroll
+          for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(f1[a], fb[0][ks], acc[a][0]);
+          if (ky < 2) load_B(ch, ky + 1, 0, ks);
+          else if (more) load_B(ch + 1, 0, 0, ks);
+        }
+        continue;
+      }
       bf16x8 fa[KSTEPS][TM][NS];
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks)
@@ -323,59 +378,87 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int s = 0; s < NS; ++s)
-            fa[ks][a][s] = *reinterpret_cast<const bf16x8*>(&sV[s * PLANE_E + a_base[a] + toff + ks * 16]);
+            fa[ks][a][s] = *reinterpret_cast<const bf16x8*>(
+                &sV[s * PLANE_E + a_base[a] + toff + (SWZ ? 8 * ((lh + 2 * ks) ^ (((li >> 3) + ky) & 3)) : ks * 16)]);
       __builtin_amdgcn_sched_barrier(0);     // (all fragment reads of the tap are requested ahead of its MFMAs)
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
+#if MT_WINOX_ABL != 3
           for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(fa[ks][a], fb[tn][ks], acc[a][tn]);
+#else
+          for (int a = 0; a < TM; ++a) acc[a][tn][0] += (float)fa[ks][a][0][0] + (float)fb[tn][ks][0][0];
+#endif
+#if MT_WINOX_ABL != 4
           if (ky < 2) load_B(ch, ky + 1, tn, ks);
           else if (more) load_B(ch + 1, 0, tn, ks);
+#endif
         }
       }
     }
+    if (ch == 0) WX_STAMP(4);
     if (more) {
       __syncthreads();            // every wave is done reading this chunk's image
+      if (ch == 0) WX_STAMP(5);
       store_v();
+      if (ch == 0) WX_STAMP(6);
       __syncthreads();
+      if (ch == 0) WX_STAMP(7);
     }
   }
+  WX_STAMP(8);
 
-  // ---- epilogue: the four xi meet through LDS, one M tile at a time; wave w finishes output row 4a + w ---------
+#if MT_WINOX_ABL == 5          // (lab: no exchange, no epilogue)
+  {
+    float sacc = 0.f;
+    for (int a = 0; a < TM; ++a) for (int tn = 0; tn < TN; ++tn) for (int r = 0; r < 16; ++r) sacc += acc[a][tn][r];
+    if (sacc == 1.2345f) p.y[0] = sacc;
+    return;
+  }
+#endif
+  // ---- epilogue: the four xi meet through LDS, one M tile at a time; wave w finishes output row 4a + w of both
+  // M tiles.  Two phases (conv_common.h: halo_epi_load / halo_epi_store): no load is issued after the first store.
   float* xch = reinterpret_cast<float*>(sV);       // [xi 4][tn][16][64 lanes]
-  float vmax = 0.f;
+  float vals[TN][8 * TM];
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
     __syncthreads();                               // the image (a == 0) / the previous tile's products are dead
+    if (a == 0) WX_STAMP(11);
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int r = 0; r < 16; ++r) xch[((xi * TN + tn) * 16 + r) * 64 + lane] = acc[a][tn][r];
     __syncthreads();
+    if (a == 0) WX_STAMP(12); else WX_STAMP(14);
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      float vals[8];
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int r = 4 * xi + q;                  // C/D rows (r & 3) + 8 (r >> 2) + 4 lh: output row r >> 2 = xi of the M tile
         const float m0 = xch[((0 * TN + tn) * 16 + r) * 64 + lane], m1 = xch[((1 * TN + tn) * 16 + r) * 64 + lane];
         const float m2 = xch[((2 * TN + tn) * 16 + r) * 64 + lane], m3 = xch[((3 * TN + tn) * 16 + r) * 64 + lane];
-        vals[2 * q] = (m0 + m1 + m2) * inv;
-        vals[2 * q + 1] = (m1 - m2 - m3) * inv;
+        vals[tn][8 * a + 2 * q] = (m0 + m1 + m2) * inv;
+        vals[tn][8 * a + 2 * q + 1] = (m1 - m2 - m3) * inv;
       }
-      const int oy_ = ty0 + 4 * a + xi, oxb = tx0 + 8 * lh;
-      auto pix = [&](int e, int& oy, int& ox) {
-        oy = oy_;
-        ox = oxb + 2 * (e >> 1) + (e & 1);       // column pair (r & 3) + 4 lh
-      };
-      // (the 32-wide variant lives on occupancy: the sequential form; the 64-wide one batches the optional operands' loads)
-      if constexpr (TN == 1) vmax = fmaxf(vmax, halo_epilogue_lean<8>(p, n, n0 + tn * 32 + li, vals, pix));
-      else vmax = fmaxf(vmax, halo_epilogue<8>(p, n, n0 + tn * 32 + li, vals, pix));
-    }
+    if (a == 0) WX_STAMP(13);
   }
-  if (p.yamax) raise_amax(p.yamax, vmax);
+  auto pix = [&](int e, int& oy, int& ox) {
+    oy = ty0 + 4 * (e >> 3) + xi;
+    ox = tx0 + 8 * lh + 2 * ((e & 7) >> 1) + (e & 1);       // column pair (r & 3) + 4 lh
+  };
+  EpiOps<8 * TM> ops[TN];
+  unsigned okm[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) okm[tn] = halo_epi_load<8 * TM>(p, n, n0 + tn * 32 + li, pix, ops[tn]);
+  float vmax = 0.f;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+    vmax = fmaxf(vmax, halo_epi_store<8 * TM>(p, n, n0 + tn * 32 + li, vals[tn], pix, bv[tn], ops[tn], okm[tn]));
+  WX_STAMP(9);
+  finish_amax(p, vmax, sV);
+  WX_STAMP(10);
 }
 
 // ---- 16 x 16-pixel tiles, 8 waves, double-buffered image ------------------------------------
@@ -415,7 +498,10 @@ __global__ __launch_bounds__(512, 2) void igemm_wino16_kernel(ConvK p, int tiles
     // this XCD's blocks: lid = tile_local * ntn + n-tile; the grid is padded to 8 * ceil(...) blocks
     const int tl = lid / ntn;
     nty = lid - tl * ntn;
-    if (tl >= mine) return;
+    if (tl >= mine) {            // (a padding block: it still takes part in the launch's max reduction)
+      finish_amax(p, 0.f, sV);
+      return;
+    }
     bid = start + tl;
   }
   const int tx_ = bid % tiles_x; bid /= tiles_x;
@@ -561,7 +647,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino16_kernel(ConvK p, int tiles
       ox = oxb + 2 * (r & 3) + j;
     }));
   }
-  if (p.yamax) raise_amax(p.yamax, vmax);
+  finish_amax(p, vmax, sV);
 }
 
 }  // namespace
@@ -619,3 +705,9 @@ void mt_halo_wino_launch(const void* kp, int fmt, void* stream) {
     else hipLaunchKernelGGL((igemm_halo_wino_kernel<0, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
   }
 }
+
+#if MT_WINOX_TRACE
+extern "C" int mt_lab_winox_trace(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(winox_trace), sizeof(unsigned long long) * n);
+}
+#endif

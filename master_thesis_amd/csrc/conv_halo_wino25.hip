@@ -57,7 +57,10 @@ __global__ __launch_bounds__(512, 2) void igemm_wino25_kernel(ConvK p, int tiles
     const int mine = q8 + (xcd < r8 ? 1 : 0), start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int tl = lid / ntn;
     nty = lid - tl * ntn;
-    if (tl >= mine) return;
+    if (tl >= mine) {            // (a padding block: it still takes part in the launch's max reduction)
+      finish_amax(p, 0.f, sV);
+      return;
+    }
     bid = start + tl;
   }
   const int tx_ = bid % tiles_x; bid /= tiles_x;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino25_kernel(ConvK p, int tiles
     oy = oyb + (r >> 2);
     ox = oxb + 2 * (r & 3) + j;
   });
-  if (p.yamax) raise_amax(p.yamax, vmax);
+  finish_amax(p, vmax, sV);
 }
 
 __global__ void weight_pack_halo_wino25_kernel(const float* src, int A, int B, long sa, long sb, long st, __bf16* dst,

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_tiny_in_kernel(ConvK p, const float*
       }
     }
   }
-  if (p.yamax) raise_amax(p.yamax, vmax);
+  finish_amax(p, vmax, sX);
 }
 
 // ---- weight gradient: stride-1 3x3 "same", one side with <= 4 real channels, the other 64 or 128 wide ------
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void conv_tiny_out_kernel(ConvK p, const float
       if (iy + 1 < iy_end) row(xb, xa, iy + 1);
     }
   }
-  if (p.yamax) raise_amax(p.yamax, vmax);
+  finish_amax(p, vmax, sW);
 }
 
 bool tiny_enabled() {
@@ -385,6 +385,7 @@ extern "C" int mt_conv_tiny_in_run(const mt_conv* d, const float* w, int32_t cin
   MT_REQUIRE(!d->res.p && !d->accumulate && d->dact_c0 == 0, "mt_conv_tiny_in_run: no residual / accumulate / partial gating");
   MT_REQUIRE(!d->bias || (reinterpret_cast<uintptr_t>(d->bias) & 15) == 0, "mt_conv_tiny_in_run: bias must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (k.yamax) k.ascr = mt_amax_scratch(s);
   const int rows = d->y.C == 128 ? 8 : 16;
   const int tiles_y = (k.Ho + rows - 1) / rows, tiles_x = (k.Wo + 15) / 16;
   const long nt = (long)k.N * tiles_y * tiles_x;
@@ -452,6 +453,7 @@ extern "C" int mt_conv_tiny_out_run(const mt_conv* d, const float* w, int32_t co
   MT_REQUIRE(co_off >= 0 && co_off + cout <= d->y.C && (!zero_fill || co_off == 0), "mt_conv_tiny_out_run: channel window outside y");
   MT_REQUIRE(!d->res.p && !d->accumulate && !d->dsrc.p, "mt_conv_tiny_out_run: no residual / accumulate / gating");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (k.yamax) k.ascr = mt_amax_scratch(s);
   // vertical segments: tall enough that the KS - 1 halo rows are a small share, short enough for >= 4096 work items
   const int strips_x = (k.Wo + 7) / 8;
   // (measured at 256^2: 8 .. 128 rows per segment all within 10 %; at 64^2 only the short segments fill the chip)

@@ -176,9 +176,16 @@ __device__ __forceinline__ void wave_raise_amax(float v, float* out) {
   if ((threadIdx.x & 63) == 0 && v > __builtin_nontemporal_load(out))
     atomicMax(reinterpret_cast<int*>(out), __float_as_int(v));
 }
+// block maximum raised into a device scalar: two levels through the stream's scratch (common.h: raise_amax_block --
+// same-address atomics cost 11 ns each, a 2048-block launch spent 22 us in them) when there is one.  All threads call it.
+__device__ __forceinline__ void block_raise_amax(float v, float* out, AmaxScratch* scr) {
+  __shared__ float red[16];
+  if (scr) raise_amax_block(out, scr, v, red, blockIdx.x, gridDim.x);
+  else wave_raise_amax(v, out);
+}
 
 __global__ void axpby_kernel(V3 x, float a, V3 z, float b, float* y, long yn, long yh, long yw, int N, int H, int W,
-                             int C4, float* yamax) {
+                             int C4, float* yamax, AmaxScratch* scr) {
   const PxWalk w(C4);
   const unsigned P = (unsigned)N * H * W;
   float m = 0.f;
@@ -189,7 +196,7 @@ __global__ void axpby_kernel(V3 x, float a, V3 z, float b, float* y, long yn, lo
       *reinterpret_cast<f32x4*>(y + px_off(yn, yh, yw, H, W, p) + w.c) = v;
       m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     }
-  if (yamax) wave_raise_amax(m, yamax);
+  if (yamax) block_raise_amax(m, yamax, scr);
 }
 
 __global__ void dact_kernel(V3 x, V3 s, int act, float* y, long yn, long yh, long yw, int N, int H, int W, int C4) {
@@ -647,8 +654,12 @@ __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, lo
 }
 
 // max |x| into a device scalar (non-negative floats order like their bit patterns)
-__device__ __forceinline__ void block_amax(float v, float* out) {
-  __shared__ float part[8];
+__device__ __forceinline__ void block_amax(float v, float* out, AmaxScratch* scr) {
+  __shared__ float part[16];
+  if (scr) {
+    raise_amax_block(out, scr, v, part, blockIdx.x, gridDim.x);
+    return;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
@@ -660,7 +671,8 @@ __device__ __forceinline__ void block_amax(float v, float* out) {
   }
 }
 
-__global__ void absmax_view_kernel(const float* x, long sn, long sh, long sw, int N, int H, int W, int C4, float* out) {
+__global__ void absmax_view_kernel(const float* x, long sn, long sh, long sw, int N, int H, int W, int C4, float* out,
+                                   AmaxScratch* scr) {
   const PxWalk w(C4);
   const unsigned P = (unsigned)N * H * W;
   float m = 0.f;
@@ -669,14 +681,14 @@ __global__ void absmax_view_kernel(const float* x, long sn, long sh, long sw, in
       const f32x4 v = *reinterpret_cast<const f32x4*>(x + px_off(sn, sh, sw, H, W, p) + w.c);
       m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     }
-  block_amax(m, out);
+  block_amax(m, out, scr);
 }
 
-__global__ void absmax_flat_kernel(const float* x, long n, float* out) {
+__global__ void absmax_flat_kernel(const float* x, long n, float* out, AmaxScratch* scr) {
   float m = 0.f;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     m = fmaxf(m, fabsf(x[i]));
-  block_amax(m, out);
+  block_amax(m, out, scr);
 }
 
 // 3D softmax of the correlation volume (model_dfpn.py:567-583): row = (clip b, target position pt),
@@ -841,7 +853,7 @@ extern "C" int mt_axpby(const mt_view* x, float a, const mt_view* z, float b, co
   const long total = (long)y->N * y->H * y->W * (y->C / 4);
   hipLaunchKernelGGL(axpby_kernel, dim3(mt_grid_1d(total, 256)), dim3(256), 0, S_(stream), v3(x), a,
                      v3(z && z->p ? z : nullptr), b, y->p, (long)y->sn, (long)y->sh, (long)y->sw, y->N, y->H, y->W,
-                     y->C / 4, y_amax);
+                     y->C / 4, y_amax, y_amax ? mt_amax_scratch(S_(stream)) : nullptr);
   return mt_check_launch("mt_axpby");
 }
 
@@ -992,12 +1004,13 @@ extern "C" int mt_absmax(const mt_view* x, float* out, void* stream) {
   MT_REQUIRE(x->C <= 1024 && (int64_t)x->N * x->H * x->W < (1ll << 31), "mt_absmax: more than 1024 channels or 2^31 pixels");
   const long total = (long)x->N * x->H * x->W * (x->C / 4);
   hipLaunchKernelGGL(absmax_view_kernel, dim3(mt_grid_1d(total, 256, 2048)), dim3(256), 0, S_(stream), x->p,
-                     (long)x->sn, (long)x->sh, (long)x->sw, x->N, x->H, x->W, x->C / 4, out);
+                     (long)x->sn, (long)x->sh, (long)x->sw, x->N, x->H, x->W, x->C / 4, out, mt_amax_scratch(S_(stream)));
   return mt_check_launch("mt_absmax");
 }
 
 extern "C" int mt_absmax_flat(const float* p, int64_t n, float* out, void* stream) {
   MT_REQUIRE(p && out && n > 0, "mt_absmax_flat: bad arguments");
-  hipLaunchKernelGGL(absmax_flat_kernel, dim3(mt_grid_1d(n, 256, 1024)), dim3(256), 0, S_(stream), p, (long)n, out);
+  hipLaunchKernelGGL(absmax_flat_kernel, dim3(mt_grid_1d(n, 256, 1024)), dim3(256), 0, S_(stream), p, (long)n, out,
+                     mt_amax_scratch(S_(stream)));
   return mt_check_launch("mt_absmax_flat");
 }

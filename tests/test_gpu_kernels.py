@@ -251,6 +251,46 @@ def test_conv5x5_f16x3_is_fp32_grade(mt, case):
     assert e_fwd < 4e-6 and e_bwd < 4e-6, (e_fwd, e_bwd, e_ref)
 
 
+AMAX_CASES = [
+    # (N, H, W, cin, cout, k, stride): one per forward / backward-data kernel family, plus ragged images whose padded
+    # grids have blocks without a tile (they still take part in the two-level reduction) and launches under 64 blocks
+    (4, 64, 64, 64, 32, 3, 1), (4, 64, 64, 160, 32, 3, 1), (4, 64, 64, 192, 64, 3, 1), (2, 128, 128, 128, 128, 3, 1),
+    (2, 128, 128, 128, 128, 5, 1), (2, 64, 64, 128, 256, 3, 1), (64, 16, 16, 256, 256, 3, 1), (2, 128, 128, 10, 128, 5, 1),
+    (2, 128, 128, 128, 2, 5, 1), (2, 128, 128, 128, 1, 3, 1), (2, 128, 128, 3, 64, 3, 1), (2, 128, 128, 128, 128, 5, 2),
+    (2, 128, 128, 64, 64, 3, 2), (2, 64, 64, 64, 64, 3, 1), (1, 40, 56, 128, 128, 3, 1), (1, 40, 56, 128, 128, 5, 1),
+    (3, 24, 40, 96, 32, 3, 1), (2, 64, 64, 32, 32, 3, 1), (1, 8, 16, 64, 32, 3, 1), (1, 21, 13, 128, 128, 5, 2),
+    (1, 13, 19, 256, 256, 3, 1),
+]
+
+
+@pytest.mark.parametrize('case', AMAX_CASES)
+def test_output_amax_scalars(mt, case):
+    """Every f16x3 launch raises a device scalar to max|output| (the next layer's power-of-two scale).  The kernels
+    reduce it in two levels through a per-stream scratch (csrc/common.h: raise_amax_block): the scalar must equal
+    torch's max over what the launch wrote -- twice in a row (the scratch is left clean) and for both directions."""
+    from master_thesis_amd import engine as E
+    n, h, w, cin, cout, k, st = case
+    with E.precision('f16x3'):
+        for rep in range(2):
+            spec = E.LayerSpec('c', cin, cout, k, st, k // 2)
+            x = torch.randn((n, h, w, E.cpad(cin)), device=dev()) * (1 + rep)
+            x[..., cin:] = 0
+            wt = torch.randn((cout, cin, k, k), device=dev()) * 0.05
+            b = torch.randn((cout,), device=dev())
+            y = E.conv_forward(spec, E.view_of(x), x.shape[:3], wt, b)
+            ref = float(y[..., :cout].abs().max())
+            assert abs(float(y._mt_amax) - ref) <= 1e-6 * ref, ('forward', rep, float(y._mt_amax), ref)
+            dz = torch.randn_like(y) * 3
+            dz[..., cout:] = 0
+            dx = torch.zeros_like(x)
+            E.conv_backward_data(spec, dz, wt, E.view_of(dx))
+            ref = float(dx[..., :cin].abs().max())
+            assert abs(float(dx._mt_amax) - ref) <= 1e-6 * ref, ('backward', rep, float(dx._mt_amax), ref)
+            # the stand-alone reduction and the element-wise kernel that carries one
+            a = E.absmax_into(y, E.new_amax(y.device))
+            assert float(a) == float(y.abs().max())
+
+
 def test_tiny_exit_layer_gates_by_the_saved_activation(mt):
     """conv(64 -> 128, ReLU) -> conv(128 -> 2): the backward-data of the 2-channel exit runs on the fp32 VALU
     kernel and gates by ReLU'(saved output) in its epilogue (model_dfpn.py:708-710)."""
