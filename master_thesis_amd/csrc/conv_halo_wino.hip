@@ -208,20 +208,17 @@ __device__ unsigned long long winox_trace[4096 * 16];
 #else
 #define WX_STAMP(i) do {} while (0)
 #endif
-#ifndef MT_WINOX_OCC1
-#define MT_WINOX_OCC1 3
+#ifndef MT_WINOX_SHADOW       // split form of the transform (conv_common.h: split4f SHADOW): 1 = no instruction that shares the matrix pipe
+#define MT_WINOX_SHADOW 2
 #endif
-#ifndef MT_WINOX_ABL          // (lab ablations: 1 no halo loads, 2 no transform / split / image stores, 3 no MFMAs, 4 no weight loads)
+#ifndef MT_WINOX_ABL          // (lab ablations: 1 no halo loads, 2 no transform / split / image stores, 3 no MFMAs, 4 no weight loads, 5 no epilogue)
 #define MT_WINOX_ABL 0
 #endif
 template <int FMT, int TN>
-__global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC1 : 2) void igemm_winox_kernel(ConvK p, int tiles_y, int tiles_x) {
+__global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK p, int tiles_y, int tiles_x) {
   constexpr int NS = 2, CK = 32, TH = 8, TW = 16, BN = 32 * TN, TM = 2;
   constexpr int NTX = TW / 2, ROWS = TH + 2;
-  // TN == 1: the 16-byte slots of an entry are XOR-swizzled by the row instead of padding the rows by 16 bytes: the image
-  // is 40960 bytes exactly, FOUR blocks share the 160 KB of a CU
-  constexpr bool SWZ = TN == 1;
-  constexpr int ENT = CK, ROW_E = 4 * NTX * ENT + (SWZ ? 0 : 8), PLANE_E = ROWS * ROW_E;
+  constexpr int ENT = CK, ROW_E = 4 * NTX * ENT + 8, PLANE_E = ROWS * ROW_E;
   constexpr int NIT = ROWS * NTX * (CK / 4), RI = (NIT + 255) / 256;
   constexpr int KSTEPS = CK / 16;
   static_assert(4 * TN * 16 * 64 * 4 <= NS * PLANE_E * 2, "the epilogue exchange of one M tile must fit the image");
@@ -244,44 +241,40 @@ __global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC1 : 2) void igemm_winox_
   const float inv = FMT ? 1.f / (scA * pow2_scale(*p.wamax)) : 1.f;
   const float* xin = p.x + (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
 
-  // ---- transform items: (halo row r, column pair t, channel quad c4), c4 fastest (as igemm_halo_wino_kernel)
-  int it_row[RI], it_lx[RI];
-  unsigned it_ok[RI];
+  // ---- transform items: (halo row r, column pair t, channel quad c4), c4 fastest (as igemm_halo_wino_kernel).
+  // The halo comes through BUFFER loads: a wave-uniform descriptor of image n (SGPRs) + one 32-bit byte offset per
+  // (item, pixel), computed once, + the chunk's channel offset as the scalar offset.  A pixel outside the image gets an
+  // offset beyond the descriptor's range and reads as zero: no predicate, no branch, no zero-fill and no 64-bit address
+  // arithmetic per load (the loop was VALU-bound: 508 VALU instructions per chunk against 36 MFMAs, a third of them these).
+  const unsigned xbytes = (unsigned)(((long)(p.H - 1) * p.xsh + (long)(p.W - 1) * p.xsw + ((p.C + 3) & ~3)) * 4);
+  const auto xsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, xbytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned it_off[RI][4];
 #pragma unroll
   for (int i = 0; i < RI; ++i) {
     const int q = tid + 256 * i;
     const int c4 = q & 7, t = (q >> 3) & 7, r = q >> 6;
     const int ly = ty0 - 1 + r;
-    it_ok[i] = 0;
-    it_lx[i] = tx0 - 1 + 2 * t;
-    it_row[i] = (int)((long)(ly >> p.ups) * p.xsh) + 4 * c4;
+    const long row = (long)(ly >> p.ups) * p.xsh + 4 * c4;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int lx = it_lx[i] + b;
+      const int lx = tx0 - 1 + 2 * t + b;
       const bool ok = q < NIT && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL;
-      it_ok[i] |= ok ? (1u << b) : 0u;
+      it_off[i][b] = ok ? (unsigned)((row + (long)(lx >> p.ups) * p.xsw) * 4) : OOB;
     }
   }
-  const int xsw = (int)p.xsw;
   f32x4 rh[RI][4];
   auto load_raw = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
       const int c4 = (tid + 256 * i) & 7;
-      const bool cin = c0 + 4 * c4 < p.C;
+      const unsigned cmask = c0 + 4 * c4 < p.C ? 0u : OOB;       // (the channel tail of the last chunk)
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#if MT_WINOX_ABL == 6          // (lab: half the halo registers -- WRONG results, the cost model of the lane-exchange form)
-        if (b < 2) continue;
-#endif
 #if MT_WINOX_ABL != 1
-        if (((it_ok[i] >> b) & 1u) && cin)
-          v = *reinterpret_cast<const f32x4*>(xin + (it_row[i] + ((it_lx[i] + b) >> p.ups) * xsw + c0));
-#endif
-        rh[i][b] = v;
-#if MT_WINOX_ABL == 6
-        rh[i][b - 2] = v;
+        rh[i][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsr, it_off[i][b] | cmask, c0 * 4, 0));
+#else
+        rh[i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
       }
     }
@@ -297,11 +290,11 @@ __global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC1 : 2) void igemm_winox_
         const int c4 = q & 7, t = (q >> 3) & 7, r = q >> 6;
         const f32x4 d0 = rh[i][0], d1 = rh[i][1], d2 = rh[i][2], d3 = rh[i][3];
         const f32x4 v[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
-        __bf16* dst = sV + r * ROW_E + t * ENT + (SWZ ? 8 * ((c4 >> 1) ^ (r & 3)) + 4 * (c4 & 1) : 4 * c4);
+        __bf16* dst = sV + r * ROW_E + t * ENT + 4 * c4;
 #pragma unroll
         for (int x4 = 0; x4 < 4; ++x4) {
           bf16x4 parts[NS];
-          split4f<NS, FMT>(v[x4], scA, parts);
+          split4f<NS, FMT, MT_WINOX_SHADOW>(v[x4], scA, parts);
 #pragma unroll
           for (int s = 0; s < NS; ++s)
             *reinterpret_cast<bf16x4*>(dst + s * PLANE_E + x4 * NTX * ENT) = parts[s];
@@ -331,8 +324,7 @@ __global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC1 : 2) void igemm_winox_
   // MFMA row i of M tile a = (output row 4a + (i >> 3), column pair i & 7); this wave's xi plane of the image
   int a_base[TM];
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
-    a_base[a] = (4 * a + (li >> 3)) * ROW_E + (li & 7) * ENT + (SWZ ? 0 : 8 * lh) + xi * NTX * ENT;
+  for (int a = 0; a < TM; ++a) a_base[a] = (4 * a + (li >> 3)) * ROW_E + (li & 7) * ENT + 8 * lh + xi * NTX * ENT;
 
   load_raw(0);
 #pragma unroll
@@ -354,23 +346,6 @@ __global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC1 : 2) void igemm_winox_
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int toff = ky * ROW_E;
-      if constexpr (TN == 1 && MT_WINOX_OCC1 >= 4) {   // four blocks per CU: 128 registers -- one k step of A fragments at a time
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          bf16x8 f1[TM][NS];
-#pragma unroll
-          for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-              f1[a][s] = *reinterpret_cast<const bf16x8*>(
-                  &sV[s * PLANE_E + a_base[a] + toff + 8 * ((lh + 2 * ks) ^ (((li >> 3) + ky) & 3))]);
-#pragma unroll
-          for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(f1[a], fb[0][ks], acc[a][0]);
-          if (ky < 2) load_B(ch, ky + 1, 0, ks);
-          else if (more) load_B(ch + 1, 0, 0, ks);
-        }
-        continue;
-      }
       bf16x8 fa[KSTEPS][TM][NS];
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks)
@@ -378,8 +353,7 @@ __global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC1 : 2) void igemm_winox_
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int s = 0; s < NS; ++s)
-            fa[ks][a][s] = *reinterpret_cast<const bf16x8*>(
-                &sV[s * PLANE_E + a_base[a] + toff + (SWZ ? 8 * ((lh + 2 * ks) ^ (((li >> 3) + ky) & 3)) : ks * 16)]);
+            fa[ks][a][s] = *reinterpret_cast<const bf16x8*>(&sV[s * PLANE_E + a_base[a] + toff + ks * 16]);
       __builtin_amdgcn_sched_barrier(0);     // (all fragment reads of the tap are requested ahead of its MFMAs)
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -677,7 +651,9 @@ void mt_halo_wino_launch(const void* kp, int fmt, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_y = (k.Ho + 7) / 8, tiles_x = (k.Wo + 15) / 16;
   const unsigned nt = (unsigned)k.N * tiles_y * tiles_x;
-  if (halo_winox_wanted(k.C, k.Co, 9)) {
+  // (the xi-split kernel addresses an input image through a buffer descriptor with 32-bit offsets: images under 2 GB)
+  const bool x32 = ((long)(k.H - 1) * k.xsh + (long)(k.W - 1) * k.xsw + k.C + 4) * 4 < (1L << 31);
+  if (halo_winox_wanted(k.C, k.Co, 9) && x32) {
     if (k.Co > 32) {
       if (fmt) hipLaunchKernelGGL((igemm_winox_kernel<1, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
       else hipLaunchKernelGGL((igemm_winox_kernel<0, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);

@@ -934,7 +934,8 @@ extern "C" int mt_resize_bilinear_bwd(const float* ddst, int64_t d_plane, int64_
 extern "C" int mt_l1_fwd(const float* a, const float* b, const float* mask, const float* w, int32_t B, int32_t C,
                          int32_t MC, int64_t S, int32_t count_mask, float* acc, void* stream) {
   MT_REQUIRE(a && b && acc && B > 0 && C > 0 && S > 0 && (MC == 1 || MC == C), "mt_l1_fwd: bad arguments");
-  hipLaunchKernelGGL(l1_fwd_kernel, dim3(mt_grid_1d((long)B * C * S, 256, 1024)), dim3(256), 0, S_(stream), a, b, mask,
+  // (one block per CU: every block ends in one or two atomics on the same address, 11 ns each at the memory side)
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(mt_grid_1d((long)B * C * S, 256, 256)), dim3(256), 0, S_(stream), a, b, mask,
                      w, B, C, MC, (long)S, count_mask, acc);
   return mt_check_launch("mt_l1_fwd");
 }
@@ -952,7 +953,7 @@ extern "C" int mt_l1_bwd(const float* a, const float* b, const float* mask, cons
 extern "C" int mt_sobel_l1_fwd(const float* a, const float* b, int32_t NP, int32_t H, int32_t W, float* acc,
                                void* stream) {
   MT_REQUIRE(a && b && acc && NP > 0 && H > 0 && W > 0, "mt_sobel_l1_fwd: bad arguments");
-  hipLaunchKernelGGL(sobel_l1_fwd_kernel, dim3(mt_grid_1d((long)NP * H * W, 256, 1024)), dim3(256), 0, S_(stream), a,
+  hipLaunchKernelGGL(sobel_l1_fwd_kernel, dim3(mt_grid_1d((long)NP * H * W, 256, 256)), dim3(256), 0, S_(stream), a,
                      b, NP, H, W, acc);
   return mt_check_launch("mt_sobel_l1_fwd");
 }

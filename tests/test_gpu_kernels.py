@@ -84,6 +84,12 @@ CONV_CASES = [
     (1, 16, 16, 256, 256, 5, 1, 'c', 1),
     (2, 40, 24, 128, 128, 5, 1, 'c', 2),
     (1, 7, 37, 64, 128, 5, 1, 'c', 0),
+    # the pipelined xi-split kernel (launches with >= 256 tiles of 16 x 16): 32- and 64-wide tiles, ragged tiles, a last
+    # chunk of 16 channels, one chunk of look-ahead only (64 gathered channels)
+    (16, 64, 64, 64, 32, 3, 1, 'c', 2),
+    (16, 64, 64, 192, 64, 3, 1, 'c', 2),
+    (5, 100, 120, 96, 32, 3, 1, 'c', 1),
+    (9, 72, 88, 144, 64, 3, 1, 'c', 0),
 ]
 
 
@@ -259,7 +265,7 @@ AMAX_CASES = [
     (2, 128, 128, 128, 2, 5, 1), (2, 128, 128, 128, 1, 3, 1), (2, 128, 128, 3, 64, 3, 1), (2, 128, 128, 128, 128, 5, 2),
     (2, 128, 128, 64, 64, 3, 2), (2, 64, 64, 64, 64, 3, 1), (1, 40, 56, 128, 128, 3, 1), (1, 40, 56, 128, 128, 5, 1),
     (3, 24, 40, 96, 32, 3, 1), (2, 64, 64, 32, 32, 3, 1), (1, 8, 16, 64, 32, 3, 1), (1, 21, 13, 128, 128, 5, 2),
-    (1, 13, 19, 256, 256, 3, 1),
+    (1, 13, 19, 256, 256, 3, 1), (16, 64, 64, 160, 32, 3, 1), (16, 64, 64, 192, 64, 3, 1), (5, 100, 120, 96, 32, 3, 1),
 ]
 
 
