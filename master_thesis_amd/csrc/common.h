@@ -29,7 +29,7 @@ static inline bool mt_view_flat(const mt_view* v) { return mt_view_ok(v) && v->n
 
 // Scratch of the two-level max reduction of a launch (conv_common.h: raise_amax_block): 64 slots, 256 bytes apart.
 // One per stream (launches of a stream do not overlap), zero-filled at creation; every launch leaves it zero-filled.
-struct AmaxScratch { unsigned max[64 * 64]; unsigned cnt[64 * 64]; unsigned cnt2[64]; };
+struct AmaxScratch { unsigned max[64 * 64]; unsigned cnt[64 * 64]; unsigned cnt2[64]; float sum[2][64 * 64]; };   // (sum: block_sum2)
 AmaxScratch* mt_amax_scratch(hipStream_t s);      // api.cpp; nullptr on allocation failure (callers then use raise_amax)
 
 static inline int mt_grid_1d(int64_t work, int block, int cap = 4096) {
@@ -93,6 +93,51 @@ __device__ __forceinline__ void raise_amax_block(float* dst, AmaxScratch* scr, f
     if (lane == 0) {
       const unsigned z = atomicExch(&scr->cnt2[0], 0u);
       if (mm > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(mm) + (z >> 31));
+    }
+  }
+}
+
+// Two block sums of a launch added to two device scalars (t1 may be null) through the same slots, for the same reason:
+// a loss kernel of 1024 blocks ended in 1024 - 2048 atomics on one address.  A block adds its sums to slot block & 63,
+// waits for the RETURNED values (the adds are performed at the memory side by then), counts the slot; the block that
+// completes the slots folds them into *t0 / *t1 with one atomic each and leaves the scratch zero-filled.
+// Every thread of every block of the launch must call it; ``red`` = 32 floats of shared memory nobody reads any more.
+__device__ __forceinline__ void block_sum2(float v0, float v1, float* t0, float* t1, AmaxScratch* scr, float* red,
+                                           unsigned bid, unsigned nblocks) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  __syncthreads();
+  if (lane == 0) { red[wave] = v0; red[16 + wave] = v1; }
+  __syncthreads();
+  if (wave != 0) return;
+  float s0 = lane < nw ? red[lane] : 0.f, s1 = lane < nw ? red[16 + lane] : 0.f;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+  const unsigned nslots = nblocks < 64u ? nblocks : 64u;
+  unsigned fin = 0;
+  if (lane == 0) {
+    const unsigned slot = bid & 63u, members = (nblocks >> 6) + (slot < (nblocks & 63u) ? 1u : 0u);
+    const float w0 = atomicAdd(&scr->sum[0][slot * 64], s0);
+    const float w1 = t1 ? atomicAdd(&scr->sum[1][slot * 64], s1) : 0.f;
+    asm volatile("" :: "v"(w0), "v"(w1));              // the returned values are waited for here: both adds are performed
+    const unsigned old = atomicAdd(&scr->cnt[slot * 64], 1u);
+    if (old + 1 == members) {
+      const unsigned z = atomicExch(&scr->cnt[slot * 64], 0u);
+      fin = atomicAdd(&scr->cnt2[0], 1u + (z >> 31)) + 1 == nslots;
+    }
+  }
+  fin = __shfl(fin, 0, 64);
+  if (fin) {
+    float a0 = lane < (int)nslots ? atomicExch(&scr->sum[0][lane * 64], 0.f) : 0.f;
+    float a1 = (t1 && lane < (int)nslots) ? atomicExch(&scr->sum[1][lane * 64], 0.f) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); }
+    if (lane == 0) {
+      const unsigned z = atomicExch(&scr->cnt2[0], 0u);
+      asm volatile("" :: "v"(z));
+      atomicAdd(t0, a0);
+      if (t1) atomicAdd(t1, a1);
     }
   }
 }

@@ -534,7 +534,7 @@ __device__ __forceinline__ void block_add(float v, float* target) {
 }
 
 __global__ void l1_fwd_kernel(const float* a, const float* b, const float* mask, const float* w, int B, int C, int MC,
-                              long S, int count_mask, float* acc) {
+                              long S, int count_mask, float* acc, AmaxScratch* scr) {
   const long total = (long)B * C * S;
   float s = 0.f, ms = 0.f;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -546,6 +546,11 @@ __global__ void l1_fwd_kernel(const float* a, const float* b, const float* mask,
     float wt = w ? w[bi] : 1.f;
     s += wt * fabsf(a[e] * m - b[e] * m);
     if (count_mask && (MC != 1 || c == 0)) ms += wt * m;
+  }
+  if (scr) {
+    __shared__ float red[32];
+    block_sum2(s, ms, acc, count_mask ? acc + 1 : nullptr, scr, red, blockIdx.x, gridDim.x);
+    return;
   }
   block_add(s, acc);
   if (count_mask) block_add(ms, acc + 1);
@@ -585,7 +590,7 @@ __device__ __forceinline__ void sobel_at(const float* a, const float* b, int y, 
   *gv = (d[0][0] + 2.f * d[0][1] + d[0][2]) - (d[2][0] + 2.f * d[2][1] + d[2][2]);
 }
 
-__global__ void sobel_l1_fwd_kernel(const float* a, const float* b, int NP, int H, int W, float* acc) {
+__global__ void sobel_l1_fwd_kernel(const float* a, const float* b, int NP, int H, int W, float* acc, AmaxScratch* scr) {
   const long HW = (long)H * W, total = (long)NP * HW;
   float s = 0.f;
   for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -594,6 +599,11 @@ __global__ void sobel_l1_fwd_kernel(const float* a, const float* b, int NP, int 
     float gh, gv;
     sobel_at(a + pl * HW, b + pl * HW, y, x, H, W, &gh, &gv);
     s += fabsf(gh) + fabsf(gv);
+  }
+  if (scr) {
+    __shared__ float red[32];
+    block_sum2(s, 0.f, acc, nullptr, scr, red, blockIdx.x, gridDim.x);
+    return;
   }
   block_add(s, acc);
 }
@@ -934,9 +944,8 @@ extern "C" int mt_resize_bilinear_bwd(const float* ddst, int64_t d_plane, int64_
 extern "C" int mt_l1_fwd(const float* a, const float* b, const float* mask, const float* w, int32_t B, int32_t C,
                          int32_t MC, int64_t S, int32_t count_mask, float* acc, void* stream) {
   MT_REQUIRE(a && b && acc && B > 0 && C > 0 && S > 0 && (MC == 1 || MC == C), "mt_l1_fwd: bad arguments");
-  // (one block per CU: every block ends in one or two atomics on the same address, 11 ns each at the memory side)
-  hipLaunchKernelGGL(l1_fwd_kernel, dim3(mt_grid_1d((long)B * C * S, 256, 256)), dim3(256), 0, S_(stream), a, b, mask,
-                     w, B, C, MC, (long)S, count_mask, acc);
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(mt_grid_1d((long)B * C * S, 256, 1024)), dim3(256), 0, S_(stream), a, b, mask,
+                     w, B, C, MC, (long)S, count_mask, acc, mt_amax_scratch(S_(stream)));
   return mt_check_launch("mt_l1_fwd");
 }
 
@@ -953,8 +962,8 @@ extern "C" int mt_l1_bwd(const float* a, const float* b, const float* mask, cons
 extern "C" int mt_sobel_l1_fwd(const float* a, const float* b, int32_t NP, int32_t H, int32_t W, float* acc,
                                void* stream) {
   MT_REQUIRE(a && b && acc && NP > 0 && H > 0 && W > 0, "mt_sobel_l1_fwd: bad arguments");
-  hipLaunchKernelGGL(sobel_l1_fwd_kernel, dim3(mt_grid_1d((long)NP * H * W, 256, 256)), dim3(256), 0, S_(stream), a,
-                     b, NP, H, W, acc);
+  hipLaunchKernelGGL(sobel_l1_fwd_kernel, dim3(mt_grid_1d((long)NP * H * W, 256, 1024)), dim3(256), 0, S_(stream), a,
+                     b, NP, H, W, acc, mt_amax_scratch(S_(stream)));
   return mt_check_launch("mt_sobel_l1_fwd");
 }
 
