@@ -28,9 +28,9 @@ LRELU, NONE = L.ACT_LRELU, L.ACT_NONE
 
 
 def _axpby(x, a, z, b, out, amax=None):
-    """out = a*x + b*z; ``amax``: optional device scalar the launch raises to max|out|.  (Not used
-    by default: a streaming kernel's waves all finish together, and their atomics on one scalar cost
-    more than the separate mt_absmax pass -- measured +10 ms per CHN step.)"""
+    """out = a*x + b*z; ``amax``: optional device scalar the launch raises to max|out| (two-level
+    reduction through the stream's scratch, csrc/common.h: raise_amax_block -- with one atomic per
+    wave on the scalar itself this cost +10 ms per CHN step and a separate mt_absmax pass was cheaper)."""
     L.call('mt_axpby', C.byref(E.view_of(x)), a, C.byref(E.view_of(z)) if z is not None else None, b,
            C.byref(E.view_of(out)), L.ptr(amax), L.stream_ptr())
     return out
@@ -100,8 +100,7 @@ class RRDBNetFn(torch.autograd.Function):
                 bufs.append((buf, buf_amax))
                 buf, buf_amax = nxt, nxt_amax
             # 0.2 * y + x  (:585), in place in the next block's x window
-            _axpby(buf[..., :nf], 0.2, rrdb_x, 1.0, buf[..., :nf])
-            track(buf[..., :nf], buf_amax)
+            _axpby(buf[..., :nf], 0.2, rrdb_x, 1.0, buf[..., :nf], amax=buf_amax if f16 else None)
         z = buf[..., :nf]
         y = conv('trunk_conv', z, nf, nf, res=f0, alpha=1.0, beta=1.0, x_amax=buf_amax)   # (:548)
         u1 = conv('upconv1', y, nf, nf, act=LRELU, ups=1)                        # (:549-551)
@@ -209,9 +208,7 @@ class RRDBNetFn(torch.autograd.Function):
                 with torch.cuda.stream(streams[c]):
                     cur = pool[idx % len(pool)][halves[c]][..., :nf]
                     rrdb_x = pool[(idx - 3) % len(pool)][halves[c]][..., :nf]
-                    _axpby(cur, 0.2, rrdb_x, 1.0, cur)              # 0.2 * y + x  (:585)
-                    if f16:
-                        E.absmax_into(cur, a_(c, idx))
+                    _axpby(cur, 0.2, rrdb_x, 1.0, cur, amax=a_(c, idx) if f16 else None)     # 0.2 * y + x  (:585)
         RRDBNetFn._join(streams)
         merged = torch.stack(amax).amax(0) if f16 else None
         bufs = [(pool[i], merged[i:i + 1] if f16 else None) for i in range(nbuf - 1)] if keep else [None]
@@ -281,9 +278,7 @@ class RRDBNetFn(torch.autograd.Function):
                 with torch.cuda.stream(streams[c]):
                     sl = halves[c]
                     # rdb3: dz5 = 0.2 * (0.2 * drr); rdb2 / rdb1 get theirs from the launch that ends the block before
-                    _axpby(drr[sl], 0.04, drr[sl], 0.0, dzbs[bidx][sl][..., :nf])
-                    if f16:
-                        E.absmax_into(dzbs[bidx][sl][..., :nf], a_(c, bidx))
+                    _axpby(drr[sl], 0.04, drr[sl], 0.0, dzbs[bidx][sl][..., :nf], amax=a_(c, bidx) if f16 else None)
             for j in (3, 2, 1):
                 key = f'rrdb_trunk.{k}.rdb{j}.'
                 buf, buf_amax = bufs[3 * k + (j - 1)]
@@ -443,9 +438,7 @@ class RRDBNetFn(torch.autograd.Function):
                     dbuf, dbuf2 = torch.empty_like(dbuf), torch.empty_like(dbuf)
                 dzb, dzn = dbuf, dbuf2
                 dba = E.new_amax(dy.device) if f16 else None
-                _axpby(drr, 0.04, drr, 0.0, dzb[..., :nf])
-                if f16:
-                    E.absmax_into(dzb[..., :nf], dba)
+                _axpby(drr, 0.04, drr, 0.0, dzb[..., :nf], amax=dba)
                 for j in (3, 2, 1):
                     key = f'rrdb_trunk.{k}.rdb{j}.'
                     buf, buf_amax = bufs[3 * k + (j - 1)]
@@ -458,9 +451,7 @@ class RRDBNetFn(torch.autograd.Function):
                         if wbatch is not None:
                             dzb = torch.empty_like(dzb)
                         dba = E.new_amax(dy.device) if f16 else None
-                        _axpby(d_rdb, 0.2, d_rdb, 0.0, dzb[..., :nf])
-                        if f16:
-                            E.absmax_into(dzb[..., :nf], dba)
+                        _axpby(d_rdb, 0.2, d_rdb, 0.0, dzb[..., :nf], amax=dba)
                 dcur = _axpby(d_rdb, 1.0, drr, 1.0, torch.empty_like(drr))
                 continue
             for j in (3, 2, 1):
