@@ -754,6 +754,28 @@ def inplace_grad(p):
     return None
 
 
+def _batch_splits(blocks, n, ntiles, cus=256):
+    """Pixel ranges per (tile, problem) of a batched weight-gradient grid.  The kernel runs ONE block per CU (132 KB of
+    LDS), so the grid executes in rounds of ``cus`` blocks and a round costs one block's pixel tiles (+ ~24 tiles' worth of
+    pipeline fill and the 147 KB slab it writes): pick the count that minimises rounds x tiles per block instead of the one
+    that merely reaches a block target -- 180 (tile, problem) pairs x 3 ranges = 540 blocks ran as three rounds of which the
+    last was a tenth full (measured: 14.1 -> see DESIGN.md section 3, "Batched weight gradients")."""
+    forced = os.environ.get('MT355_WGRAD_BATCH_SPLITS')
+    if forced == 'old':
+        return max(1, min((WGRAD_PC_BLOCKS + blocks * n - 1) // (blocks * n), ntiles // 8 if ntiles >= 8 else 1, 256))
+    if forced:
+        return max(1, int(forced))
+    best = (None, 1)
+    for s_ in range(1, 65):
+        if s_ > 1 and ntiles // s_ < 8:
+            break
+        rounds = -(-(blocks * n * s_) // cus)
+        cost = rounds * (-(-ntiles // s_) + 24)
+        if best[0] is None or cost < best[0]:
+            best = (cost, s_)
+    return best[1]
+
+
 class WgradBatch:
     """Weight gradients that do not depend on one another (the dense blocks of the RRDB trunk),
     recorded during the backward chain and launched afterwards: one mt_wgrad_run_batch grid per
@@ -780,7 +802,7 @@ class WgradBatch:
                 chunk = group[c0: c0 + L.WGRAD_BATCH_MAX]
                 n = len(chunk)
                 _, d0, _, _, blocks, ntiles, per, kname, _ = chunk[0]
-                splits = max(1, min((WGRAD_PC_BLOCKS + blocks * n - 1) // (blocks * n), ntiles // 8 if ntiles >= 8 else 1, 256))
+                splits = _batch_splits(blocks - bin(int(d0.skip_tiles)).count('1'), n, ntiles)
                 slabs = torch.empty((n * splits * per,), device=torch.device('cuda', torch.cuda.current_device()),
                                     dtype=torch.float32)
                 arr = (L.Wgrad * n)()
