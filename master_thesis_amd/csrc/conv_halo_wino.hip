@@ -18,6 +18,7 @@
 // whose ds_read_b128 fragment reads are bank-conflict free; weight fragments come straight from
 // global memory in MFMA operand order (mt_weight_pack_halo writes G g in that order).
 #include <cstdlib>
+#include <type_traits>
 #include "conv_common.h"
 
 namespace {
@@ -340,48 +341,113 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK
   WX_STAMP(2);
   __syncthreads();
   WX_STAMP(3);
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const bool more = ch + 1 < nchunk;
-    if (more) load_raw((ch + 1) * CK);          // in flight under the three taps
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int toff = ky * ROW_E;
-      bf16x8 fa[KSTEPS][TM][NS];
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int s = 0; s < NS; ++s)
-            fa[ks][a][s] = *reinterpret_cast<const bf16x8*>(&sV[s * PLANE_E + a_base[a] + toff + ks * 16]);
-      __builtin_amdgcn_sched_barrier(0);     // (all fragment reads of the tap are requested ahead of its MFMAs)
+  if constexpr (TN == 1) {
+    // 32-wide tiles: TWO sets of weight fragments, each tap's requested two taps ahead (slot = tap parity; three taps per
+    // chunk, so the parity of a chunk's first tap alternates: the chunk body exists once per parity), A fragments one k
+    // step at a time (LDS latency is a tenth of the L2's).  Issue order matters, because loads return in order (vmcnt):
+    // the next chunk's halo is requested AFTER the fragments of this chunk's last tap, so no tap waits for the halo --
+    // with one set, fetched one tap ahead and behind the halo loads, a tap waited ~0.7 us for its fragments.
+    bf16x8 fb2[KSTEPS][NS];                     // the second set (fb[0] is the first)
+    auto load_B2 = [&](bf16x8 (&f)[KSTEPS][NS], int ch, int ky) {
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
+        const bf16x8* g = wfr + (((long)(ky * 4 + xi) * nchunk + ch) * ntile_w + blockIdx.y) * (KSTEPS * NS * 64) + ks * NS * 64 + lane;
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
+        for (int s = 0; s < NS; ++s) f[ks][s] = g[s * 64];
+      }
+    };
+    load_B2(fb2, 0, 1);                         // tap 1 of chunk 0 (tap 0 is in fb[0] since the prologue)
+    auto chunk = [&](auto parity, int ch) {
+      constexpr int P = decltype(parity)::value;
+      const bool more = ch + 1 < nchunk;
+      auto tap = [&](auto kyc, bf16x8 (&cur)[KSTEPS][NS]) {
+        constexpr int ky = decltype(kyc)::value;
+        constexpr int toff = ky * ROW_E;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          bf16x8 fa[TM][NS];
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+              fa[a][s] = *reinterpret_cast<const bf16x8*>(&sV[s * PLANE_E + a_base[a] + toff + ks * 16]);
 #pragma unroll
 #if MT_WINOX_ABL != 3
-          for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(fa[ks][a], fb[tn][ks], acc[a][tn]);
+          for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(fa[a], cur[ks], acc[a][0]);
 #else
-          for (int a = 0; a < TM; ++a) acc[a][tn][0] += (float)fa[ks][a][0][0] + (float)fb[tn][ks][0][0];
-#endif
-#if MT_WINOX_ABL != 4
-          if (ky < 2) load_B(ch, ky + 1, tn, ks);
-          else if (more) load_B(ch + 1, 0, tn, ks);
+          for (int a = 0; a < TM; ++a) acc[a][0][0] += (float)fa[a][0][0] + (float)cur[ks][0][0];
 #endif
         }
+        __builtin_amdgcn_sched_barrier(0);
+#if MT_WINOX_ABL != 4
+        // this slot's next contents: the tap two on
+        if (ky == 0) load_B2(cur, ch, 2);
+        else if (more) load_B2(cur, ch + 1, ky - 1);
+#endif
+        if (ky == 0 && more) load_raw((ch + 1) * CK);      // (behind the fragments of taps 1 and 2 in the return order)
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
+      if constexpr (P == 0) { tap(K0{}, fb[0]); tap(K1{}, fb2); tap(K2{}, fb[0]); }
+      else { tap(K0{}, fb2); tap(K1{}, fb[0]); tap(K2{}, fb2); }
+      if (ch == 0) WX_STAMP(4);
+      if (more) {
+        __syncthreads();            // every wave is done reading this chunk's image
+        if (ch == 0) WX_STAMP(5);
+        store_v();
+        if (ch == 0) WX_STAMP(6);
+        __syncthreads();
+        if (ch == 0) WX_STAMP(7);
+      }
+    };
+    for (int ch = 0; ch < nchunk; ch += 2) {
+      chunk(std::integral_constant<int, 0>{}, ch);
+      if (ch + 1 < nchunk) chunk(std::integral_constant<int, 1>{}, ch + 1);
+    }
+  } else {
+  for (int ch = 0; ch < nchunk; ++ch) {
+      const bool more = ch + 1 < nchunk;
+      if (more) load_raw((ch + 1) * CK);          // in flight under the three taps
+  #pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int toff = ky * ROW_E;
+        bf16x8 fa[KSTEPS][TM][NS];
+  #pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks)
+  #pragma unroll
+          for (int a = 0; a < TM; ++a)
+  #pragma unroll
+            for (int s = 0; s < NS; ++s)
+              fa[ks][a][s] = *reinterpret_cast<const bf16x8*>(&sV[s * PLANE_E + a_base[a] + toff + ks * 16]);
+        __builtin_amdgcn_sched_barrier(0);     // (all fragment reads of the tap are requested ahead of its MFMAs)
+  #pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+  #pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+  #pragma unroll
+  #if MT_WINOX_ABL != 3
+            for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(fa[ks][a], fb[tn][ks], acc[a][tn]);
+  #else
+            for (int a = 0; a < TM; ++a) acc[a][tn][0] += (float)fa[ks][a][0][0] + (float)fb[tn][ks][0][0];
+  #endif
+  #if MT_WINOX_ABL != 4
+            if (ky < 2) load_B(ch, ky + 1, tn, ks);
+            else if (more) load_B(ch + 1, 0, tn, ks);
+  #endif
+          }
+        }
+      }
+      if (ch == 0) WX_STAMP(4);
+      if (more) {
+        __syncthreads();            // every wave is done reading this chunk's image
+        if (ch == 0) WX_STAMP(5);
+        store_v();
+        if (ch == 0) WX_STAMP(6);
+        __syncthreads();
+        if (ch == 0) WX_STAMP(7);
       }
     }
-    if (ch == 0) WX_STAMP(4);
-    if (more) {
-      __syncthreads();            // every wave is done reading this chunk's image
-      if (ch == 0) WX_STAMP(5);
-      store_v();
-      if (ch == 0) WX_STAMP(6);
-      __syncthreads();
-      if (ch == 0) WX_STAMP(7);
-    }
-  }
+}
   WX_STAMP(8);
 
 #if MT_WINOX_ABL == 5          // (lab: no exchange, no epilogue)
