@@ -36,9 +36,12 @@ AmaxScratch* mt_amax_scratch(hipStream_t s) {
   static std::mutex mu;
   static std::unordered_map<hipStream_t, AmaxScratch*> map;
   static AmaxScratch* pool = nullptr;
-  static int used = 0;
+  static int used = 0, pool_dev = -1;
   static bool failed = false;
   std::lock_guard<std::mutex> lock(mu);
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (pool && dev != pool_dev) return nullptr;      // (one process per GPU: a second device of the same process goes without)
   auto it = map.find(s);
   if (it != map.end()) return it->second;
   if (!pool && !failed) {
@@ -52,6 +55,7 @@ AmaxScratch* mt_amax_scratch(hipStream_t s) {
       pool = nullptr;
       failed = true;
     }
+    pool_dev = dev;
   }
   AmaxScratch* p = (pool && used < POOL) ? pool + used++ : nullptr;
   map[s] = p;
