@@ -31,6 +31,10 @@ static inline bool mt_view_flat(const mt_view* v) { return mt_view_ok(v) && v->n
 // One per stream (launches of a stream do not overlap), zero-filled at creation; every launch leaves it zero-filled.
 struct AmaxScratch { unsigned max[64 * 64]; unsigned cnt[64 * 64]; unsigned cnt2[64]; float sum[2][64 * 64]; };   // (sum: block_sum2)
 AmaxScratch* mt_amax_scratch(hipStream_t s);      // api.cpp; nullptr on allocation failure (callers then use raise_amax)
+#ifndef MT_AMAX_DEFER_BLOCKS     // grids from this many blocks on fold their slots in a launch of their own
+#define MT_AMAX_DEFER_BLOCKS 1024
+#endif
+void mt_amax_fold_launch(AmaxScratch* scr, float* dst, hipStream_t s);   // stream.hip: *dst = max(*dst, slots), slots = 0
 
 static inline int mt_grid_1d(int64_t work, int block, int cap = 4096) {
   int64_t g = (work + block - 1) / block;

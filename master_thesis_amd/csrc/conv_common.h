@@ -24,6 +24,7 @@ struct ConvK {
   const float* xamax; const float* wamax;   // F16X3: device scalars max|X|, max|W| (power-of-two scaling)
   float* yamax;                              // optional: raised to max|y| over the values this launch writes
   AmaxScratch* ascr;                         // kernels that reduce max|y| in two levels (raise_amax_block): the stream's scratch
+  int amax_deferred;                         // 1: waves only raise slots; the launcher folds them with mt_amax_fold_launch
 };
 
 // Raise the device scalar *dst to at least v (v >= 0; non-negative floats order like their
@@ -160,11 +161,12 @@ __device__ __forceinline__ float halo_epilogue_body(const ConvK& p, int n, int o
   return vmax;
 }
 
+// (bv: the lane's bias value, 0 without one -- kernels that finish several tiles per lane read it before their main loop,
+// so that layers without residual / accumulate / gate operands issue no load after a store)
 template <int NE, class PixFn>
-__device__ __forceinline__ float halo_epilogue(const ConvK& p, int n, int o, float (&v)[NE], PixFn pix) {
+__device__ __forceinline__ float halo_epilogue(const ConvK& p, int n, int o, float (&v)[NE], PixFn pix, float bv) {
   static_assert(NE <= 64, "one mask word");
   const bool lane_ok = o < p.Co;
-  const float bv = (p.bias && lane_ok) ? p.bias[o] : 0.f;
   unsigned long long okm = 0;                      // bit e: element e is inside the output
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
@@ -177,6 +179,10 @@ __device__ __forceinline__ float halo_epilogue(const ConvK& p, int n, int o, flo
   // interior tiles (almost all of them): no per-element predicate anywhere
   if (__all(okm == FULL)) return halo_epilogue_body<false, NE>(p, n, o, v, pix, okm);
   return halo_epilogue_body<true, NE>(p, n, o, v, pix, okm);
+}
+template <int NE, class PixFn>
+__device__ __forceinline__ float halo_epilogue(const ConvK& p, int n, int o, float (&v)[NE], PixFn pix) {
+  return halo_epilogue<NE>(p, n, o, v, pix, (p.bias && o < p.Co) ? p.bias[o] : 0.f);
 }
 
 // The same epilogue, one element at a time (no batches: few live registers).  For the small-tile
@@ -286,6 +292,15 @@ __device__ __forceinline__ float halo_epi_store(const ConvK& p, int n, int o, fl
 // of shared memory that nobody reads any more.
 __device__ __forceinline__ void finish_amax(const ConvK& p, float vmax, void* lds) {
   if (!p.yamax) return;
+  if (p.ascr && p.amax_deferred) {     // long launches: no election, no wait -- a one-wave launch behind this one folds the slots
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if ((threadIdx.x & 63) == 0 && vmax > 0.f) {
+      const unsigned w = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+      atomicMax(&p.ascr->max[(w & 63u) * 64], __float_as_uint(vmax));
+    }
+    return;
+  }
   if (p.ascr)
     raise_amax_block(p.yamax, p.ascr, vmax, reinterpret_cast<float*>(lds), blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z),
                      gridDim.x * gridDim.y * gridDim.z);
@@ -465,6 +480,7 @@ inline int fill_convk(const mt_conv* d, ConvK* k) {
   k->zb = 1; k->zdiv = 1; k->xz = k->wz = k->yz = 0; k->par = 0; k->Kp = 0;
   k->xamax = d->x_amax; k->wamax = d->w_amax; k->yamax = d->y_amax;
   k->ascr = nullptr;                 // (set by the launch functions of the kernels that use it)
+  k->amax_deferred = 0;
   return MT_OK;
 }
 

@@ -255,13 +255,17 @@ int mt_halo_planes_try_launch(const mt_conv* d, void* stream) {
     const int tiles_y = (Hc + 7) / 8, tiles_x = (Wc + 15) / 16;
     const unsigned nt = (unsigned)k.N * tiles_y * tiles_x;
     if (nt == 0) return;
+    const unsigned ntn = k.Co > 64 ? (k.Co + 127) / 128 : 1;
+    ConvK kk = k;
+    kk.amax_deferred = kk.yamax && kk.ascr && nt * ntn * nz >= 2 * MT_AMAX_DEFER_BLOCKS;   // (two blocks per CU: from four rounds on)
     if (k.Co > 64) {
-      if (fmt) hipLaunchKernelGGL((igemm_halo_planes_kernel<1, 1>), dim3(nt, (k.Co + 127) / 128, nz), dim3(256), 0, s, k, q, tiles_y, tiles_x);
-      else hipLaunchKernelGGL((igemm_halo_planes_kernel<0, 1>), dim3(nt, (k.Co + 127) / 128, nz), dim3(256), 0, s, k, q, tiles_y, tiles_x);
+      if (fmt) hipLaunchKernelGGL((igemm_halo_planes_kernel<1, 1>), dim3(nt, ntn, nz), dim3(256), 0, s, kk, q, tiles_y, tiles_x);
+      else hipLaunchKernelGGL((igemm_halo_planes_kernel<0, 1>), dim3(nt, ntn, nz), dim3(256), 0, s, kk, q, tiles_y, tiles_x);
     } else {
-      if (fmt) hipLaunchKernelGGL((igemm_halo_planes_kernel<1, 2>), dim3(nt, 1, nz), dim3(256), 0, s, k, q, tiles_y, tiles_x);
-      else hipLaunchKernelGGL((igemm_halo_planes_kernel<0, 2>), dim3(nt, 1, nz), dim3(256), 0, s, k, q, tiles_y, tiles_x);
+      if (fmt) hipLaunchKernelGGL((igemm_halo_planes_kernel<1, 2>), dim3(nt, 1, nz), dim3(256), 0, s, kk, q, tiles_y, tiles_x);
+      else hipLaunchKernelGGL((igemm_halo_planes_kernel<0, 2>), dim3(nt, 1, nz), dim3(256), 0, s, kk, q, tiles_y, tiles_x);
     }
+    if (kk.amax_deferred) mt_amax_fold_launch(kk.ascr, kk.yamax, s);
   };
   if (!d->transposed) {
     // one launch over the output; the four parity planes of X are the units

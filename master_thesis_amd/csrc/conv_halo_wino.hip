@@ -551,6 +551,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino16_kernel(ConvK p, int tiles
   const int HL = p.H << p.ups, WL = p.W << p.ups;
   const float scA = FMT ? pow2_scale(*p.xamax) : 1.f;
   const float inv = FMT ? 1.f / (scA * pow2_scale(*p.wamax)) : 1.f;
+  const float bv = (p.bias && n0 + wn * 32 + li < p.Co) ? p.bias[n0 + wn * 32 + li] : 0.f;    // (read here: no load after a store)
   const float* xin = p.x + (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
   const int xsw = (int)p.xsw;
 
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino16_kernel(ConvK p, int tiles
       const int r = e >> 1, j = e & 1;
       oy = oyb + 4 * a + (r >> 2);
       ox = oxb + 2 * (r & 3) + j;
-    }));
+    }, bv));
   }
   finish_amax(p, vmax, sV);
 }
@@ -735,8 +736,11 @@ void mt_halo_wino_launch(const void* kp, int fmt, void* stream) {
     const unsigned nt16 = (unsigned)k.N * ty16 * tiles_x, ntn = (k.Co + 127) / 128;
     // (padded so that every XCD gets the same number of block slots: gridDim.x / ntn must be the tile count)
     const unsigned grid = 8 * ((nt16 + 7) / 8) * ntn;
-    if (fmt) hipLaunchKernelGGL((igemm_wino16_kernel<1>), dim3(grid), dim3(512), 0, s, k, ty16, tiles_x);
-    else hipLaunchKernelGGL((igemm_wino16_kernel<0>), dim3(grid), dim3(512), 0, s, k, ty16, tiles_x);
+    ConvK kk = k;
+    kk.amax_deferred = kk.yamax && kk.ascr && grid >= MT_AMAX_DEFER_BLOCKS;   // (several rounds of blocks: fold the slots afterwards)
+    if (fmt) hipLaunchKernelGGL((igemm_wino16_kernel<1>), dim3(grid), dim3(512), 0, s, kk, ty16, tiles_x);
+    else hipLaunchKernelGGL((igemm_wino16_kernel<0>), dim3(grid), dim3(512), 0, s, kk, ty16, tiles_x);
+    if (kk.amax_deferred) mt_amax_fold_launch(kk.ascr, kk.yamax, s);
     return;
   }
   if (k.Co > 64) {

@@ -279,7 +279,10 @@ void mt_halo_wino25_launch(const void* kp, int fmt, void* stream) {
   const unsigned nt = (unsigned)k.N * tiles_y * tiles_x, ntn = (k.Co + 127) / 128;
   const unsigned grid = 8 * ((nt + 7) / 8) * ntn;       // (padded so that every XCD gets the same number of block slots)
   (void)fmt;                                            // (halo_wino25_wanted admits the fp16 split only)
-  hipLaunchKernelGGL((igemm_wino25_kernel<1>), dim3(grid), dim3(512), 0, s, k, tiles_y, tiles_x);
+  ConvK kk = k;
+  kk.amax_deferred = kk.yamax && kk.ascr && grid >= MT_AMAX_DEFER_BLOCKS;   // (several rounds of blocks: fold the slots afterwards)
+  hipLaunchKernelGGL((igemm_wino25_kernel<1>), dim3(grid), dim3(512), 0, s, kk, tiles_y, tiles_x);
+  if (kk.amax_deferred) mt_amax_fold_launch(kk.ascr, kk.yamax, s);
 }
 
 void mt_pack_halo_wino25_launch(const float* src, int A, int B, long sa, long sb, long st, void* dst, int nchunk, int ntile,

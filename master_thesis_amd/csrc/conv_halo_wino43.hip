@@ -33,6 +33,13 @@
 
 namespace {
 
+#if MT_W43_TRACE              // (lab: wall-clock stamps of the stages of every block, read back by mt_lab_w43_trace)
+__device__ unsigned long long w43_trace[8192 * 8];
+#define W43_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) w43_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define W43_STAMP(i) do {} while (0)
+#endif
+
 template <int FMT>
 __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles_y, int tiles_x) {
   constexpr int NS = 2, CK = 32, TH = 16, TW = 16, BN = 128, TM = 2, NXI = 6;
@@ -46,6 +53,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
   static_assert(SM_E * 2 <= 160 * 1024, "LDS");
   __shared__ __attribute__((aligned(16))) __bf16 sV[SM_E];
 
+  W43_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int xh = wave >> 2, wn = wave & 3;                 // xi half, channel quarter
@@ -73,6 +81,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
   // the transformed image carries a further 2^-4 (|B^T d| <= 10 max|x|)
   const float scA = pow2_scale(*p.xamax) * 0.0625f;
   const float inv = 1.f / (scA * pow2_scale(*p.wamax));
+  const float bv = (p.bias && n0 + wn * 32 + li < p.Co) ? p.bias[n0 + wn * 32 + li] : 0.f;    // (read here: no load after a store)
   const float* xin = p.x + (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
   const int xsw = (int)p.xsw;
 
@@ -196,11 +205,13 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
     }
     if (more) __syncthreads();      // the other image is complete, nobody reads this one any more
   };
+  W43_STAMP(1);
   for (int ch = 0; ch < nchunk; ch += 2) {
     chunk(ch, std::integral_constant<int, 0>{});
     if (ch + 1 < nchunk) chunk(ch + 1, std::integral_constant<int, 1>{});
   }
 
+  W43_STAMP(2);
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // Output transform  y0 = m0 + m1 + m2 + m3 + m4,  y1 = m1 - m2 + 2 m3 - 2 m4,  y2 = m1 + m2 + 4 m3 + 4 m4,
   // y3 = m1 - m2 + 8 m3 - 8 m4 + m5.  xi half 0 holds m0 m1 m2, half 1 m3 m4 m5: each reduces them to its shares of
@@ -232,6 +243,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
   }
   __syncthreads();
   const float* theirs = xch + ((wave ^ 4) * 64) * 64 + lane;
+  W43_STAMP(3);
   const int o = n0 + wn * 32 + li;
   float vmax = 0.f;
   auto finish = [&](const f32x16 (&m)[3]) {
@@ -252,11 +264,13 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
         const int r = 8 * hh + (e >> 2), j = e & 3;
         oy = oyb + 2 * (r >> 2);
         ox = tx0 + 4 * (r & 3) + j;
-      }));
+      }, bv));
     }
   };
   if (xh == 0) finish(acc[0]); else finish(acc[1]);
+  W43_STAMP(4);
   finish_amax(p, vmax, sV);
+  W43_STAMP(5);
 }
 
 __global__ void weight_pack_halo_wino43_kernel(const float* src, int A, int B, long sa, long sb, long st, __bf16* dst,
@@ -285,7 +299,10 @@ void mt_halo_wino43_launch(const void* kp, void* stream) {
   const int tiles_y = (k.Ho + 15) / 16, tiles_x = (k.Wo + 15) / 16;
   const unsigned nt = (unsigned)k.N * tiles_y * tiles_x, ntn = (k.Co + 127) / 128;
   const unsigned grid = 8 * ((nt + 7) / 8) * ntn;       // (padded so that every XCD gets the same number of block slots)
-  hipLaunchKernelGGL((igemm_wino43_kernel<1>), dim3(grid), dim3(512), 0, s, k, tiles_y, tiles_x);
+  ConvK kk = k;
+  kk.amax_deferred = kk.yamax && kk.ascr && grid >= MT_AMAX_DEFER_BLOCKS;   // (several rounds of blocks: fold the slots afterwards)
+  hipLaunchKernelGGL((igemm_wino43_kernel<1>), dim3(grid), dim3(512), 0, s, kk, tiles_y, tiles_x);
+  if (kk.amax_deferred) mt_amax_fold_launch(kk.ascr, kk.yamax, s);
 }
 
 void mt_pack_halo_wino43_launch(const float* src, int A, int B, long sa, long sb, long st, void* dst, int nchunk, int ntile,
@@ -294,3 +311,9 @@ void mt_pack_halo_wino43_launch(const float* src, int A, int B, long sa, long sb
   hipLaunchKernelGGL(weight_pack_halo_wino43_kernel, dim3(mt_grid_1d(tot, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      src, A, B, sa, sb, st, reinterpret_cast<__bf16*>(dst), nchunk, ntile, flip, wamax, nchunk_total, ch_off);
 }
+
+#if MT_W43_TRACE
+extern "C" int mt_lab_w43_trace(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w43_trace), sizeof(unsigned long long) * n);
+}
+#endif

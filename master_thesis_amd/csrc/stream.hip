@@ -681,6 +681,15 @@ __device__ __forceinline__ void block_amax(float v, float* out, AmaxScratch* scr
   }
 }
 
+// One wave behind a launch whose waves only raised the 64 slots (conv_common.h: finish_amax, amax_deferred): folds them
+// into the scalar and leaves them zero.  For launches of many rounds of blocks, where the in-kernel election would cost
+// every block two atomic round trips (2.3 us of a 42 us block of igemm_wino43_kernel).
+__global__ void amax_fold_kernel(AmaxScratch* scr, float* dst) {
+  float m = __uint_as_float(atomicExch(&scr->max[threadIdx.x * 64], 0u));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (threadIdx.x == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(dst), __float_as_uint(m));
+}
 __global__ void absmax_view_kernel(const float* x, long sn, long sh, long sw, int N, int H, int W, int C4, float* out,
                                    AmaxScratch* scr) {
   const PxWalk w(C4);
@@ -766,6 +775,11 @@ V3 v3(const mt_view* v) { V3 r; r.p = v ? v->p : nullptr; r.sn = v ? v->sn : 0; 
 bool same_geom(const mt_view* a, const mt_view* b) { return a->N == b->N && a->H == b->H && a->W == b->W; }
 
 }  // namespace
+
+void mt_amax_fold_launch(AmaxScratch* scr, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(amax_fold_kernel, dim3(1), dim3(64), 0, s, scr, dst);
+}
+
 
 #define S_(x) static_cast<hipStream_t>(x)
 

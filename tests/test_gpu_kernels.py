@@ -266,6 +266,8 @@ AMAX_CASES = [
     (2, 128, 128, 64, 64, 3, 2), (2, 64, 64, 64, 64, 3, 1), (1, 40, 56, 128, 128, 3, 1), (1, 40, 56, 128, 128, 5, 1),
     (3, 24, 40, 96, 32, 3, 1), (2, 64, 64, 32, 32, 3, 1), (1, 8, 16, 64, 32, 3, 1), (1, 21, 13, 128, 128, 5, 2),
     (1, 13, 19, 256, 256, 3, 1), (16, 64, 64, 160, 32, 3, 1), (16, 64, 64, 192, 64, 3, 1), (5, 100, 120, 96, 32, 3, 1),
+    # grids of >= 1024 blocks: the waves only raise slots, a one-wave launch folds them (finish_amax, amax_deferred)
+    (16, 128, 128, 128, 128, 3, 1), (8, 128, 128, 128, 128, 5, 1), (5, 120, 136, 128, 256, 3, 1), (16, 256, 256, 128, 128, 5, 2),
 ]
 
 
