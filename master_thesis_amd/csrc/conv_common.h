@@ -145,8 +145,13 @@ __device__ __forceinline__ float halo_epilogue_body(const ConvK& p, int n, int o
       pix(e, oy, ox);
       t[e] = ok(e) ? db[oy * dsh + ox * dsw] : 1.f;
     }
+    if (p.dact == MT_ACT_RELU) {                   // (kernel-uniform switch, decided once)
 #pragma unroll
-    for (int e = 0; e < NE; ++e) v[e] *= mt_dact_fn(t[e], p.dact);
+      for (int e = 0; e < NE; ++e) v[e] *= t[e] > 0.f ? 1.f : 0.f;
+    } else if (p.dact == MT_ACT_LRELU02) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) v[e] *= t[e] > 0.f ? 1.f : 0.2f;
+    }
   }
   float vmax = 0.f;
 #pragma unroll
@@ -173,7 +178,18 @@ __device__ __forceinline__ float halo_epilogue(const ConvK& p, int n, int o, flo
     int oy, ox;
     pix(e, oy, ox);
     if (lane_ok && oy < p.Ho && ox < p.Wo) okm |= 1ull << e;
-    v[e] = mt_act_fn(v[e] + bv, p.act) * p.alpha;
+  }
+  // (the activation is a kernel-uniform switch: decided once, not per element)
+  const float alpha = p.alpha;
+  if (p.act == MT_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] = (v[e] + bv) * alpha;
+  } else if (p.act == MT_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] = fmaxf(v[e] + bv, 0.f) * alpha;
+  } else {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] = mt_act_fn(v[e] + bv, p.act) * alpha;
   }
   constexpr unsigned long long FULL = NE == 64 ? ~0ull : ((1ull << (NE & 63)) - 1);
   // interior tiles (almost all of them): no per-element predicate anywhere
@@ -270,18 +286,44 @@ __device__ __forceinline__ float halo_epi_store(const ConvK& p, int n, int o, fl
   float* yb = p.y + ((long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + o);
   const int ysh = (int)p.ysh, ysw = (int)p.ysw;
   const bool dact = p.ds && o >= p.dact_c0;
+  // (activation, residual, accumulate and gate are kernel-uniform switches: decided once, not per element)
+  const float alpha = p.alpha;
+  if (p.act == MT_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] = (v[e] + bv) * alpha;
+  } else if (p.act == MT_ACT_RELU) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] = fmaxf(v[e] + bv, 0.f) * alpha;
+  } else {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] = mt_act_fn(v[e] + bv, p.act) * alpha;
+  }
+  if (p.res) {
+    const float beta = p.beta;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] += beta * t.r[e];
+  }
+  if (p.accumulate) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) v[e] += t.y[e];
+  }
+  if (dact) {
+    if (p.dact == MT_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) v[e] *= t.d[e] > 0.f ? 1.f : 0.f;
+    } else if (p.dact == MT_ACT_LRELU02) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) v[e] *= t.d[e] > 0.f ? 1.f : 0.2f;
+    }
+  }
   float vmax = 0.f;
 #pragma unroll
   for (int e = 0; e < NE; ++e) {
-    float x = mt_act_fn(v[e] + bv, p.act) * p.alpha;
-    if (p.res) x += p.beta * t.r[e];
-    if (p.accumulate) x += t.y[e];
-    if (dact) x *= mt_dact_fn(t.d[e], p.dact);
     int oy, ox;
     pix(e, oy, ox);
     if ((okm >> e) & 1) {
-      yb[oy * ysh + ox * ysw] = x;
-      vmax = fmaxf(vmax, fabsf(x));
+      yb[oy * ysh + ox * ysw] = v[e];
+      vmax = fmaxf(vmax, fabsf(v[e]));
     }
   }
   return vmax;
