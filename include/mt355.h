@@ -11,7 +11,8 @@
  *     addresses on the current HIP device; `stream` is a hipStream_t (as void*).
  *   - return 0 on success, a negative mt_status otherwise; no exceptions cross
  *     the ABI; mt_last_error() gives a thread-local message.
- *   - nothing allocates or synchronises: the caller passes workspaces.
+ *   - nothing synchronises, and the caller passes workspaces; the one allocation inside the library is a 4 MB pool of
+ *     reduction scratch (one area per stream), made by the first launch outside a graph capture.
  *   - activations inside the engine are "NHWC" engine tensors: float32,
  *     channels innermost and contiguous, the channel count padded with ZEROS.
  *     The ABI itself accepts any C % 4 == 0 (mt_view); the LDS halo-tile
