@@ -299,6 +299,53 @@ def test_output_amax_scalars(mt, case):
             assert float(a) == float(y.abs().max())
 
 
+def test_output_amax_on_concurrent_streams_and_past_the_scratch_pool(mt):
+    """The two-level reduction keeps its slots in a per-stream scratch (64 areas): launches on different streams run
+    side by side without sharing one, and a stream past the pool falls back to the filtered atomic -- the scalar is
+    torch's maximum either way."""
+    from master_thesis_amd import engine as E
+    torch.manual_seed(3)
+    streams = [torch.cuda.Stream() for _ in range(4)] + [torch.cuda.Stream(priority=-1) for _ in range(4)]
+    spec = E.LayerSpec('c', 96, 32, 3, 1, 1)
+    wt = torch.randn((32, 96, 3, 3), device=dev()) * 0.05
+    b = torch.randn((32,), device=dev())
+    with E.precision('f16x3'):
+        E.conv_forward(spec, E.view_of(torch.randn((2, 32, 32, 96), device=dev())), (2, 32, 32), wt, b)   # (the pack, on the main stream)
+        torch.cuda.synchronize()
+        for rep in range(3):
+            xs = [torch.randn((8, 64, 64, 96), device=dev()) * (1 + i + rep) for i in range(len(streams))]
+            ys = []
+            torch.cuda.synchronize()
+            for st, x in zip(streams, xs):
+                with torch.cuda.stream(st):
+                    ys.append(E.conv_forward(spec, E.view_of(x), x.shape[:3], wt, b))
+            torch.cuda.synchronize()
+            for y in ys:
+                ref = float(y[..., :32].abs().max())
+                assert abs(float(y._mt_amax) - ref) <= 1e-6 * ref, (rep, float(y._mt_amax), ref)
+        # more distinct streams than the pool has areas (torch hands out 32 per priority: external ones on top)
+        import ctypes
+        hip = ctypes.CDLL('libamdhip64.so')
+        made = []
+        try:
+            for i in range(72):
+                h = ctypes.c_void_p()
+                assert hip.hipStreamCreate(ctypes.byref(h)) == 0
+                made.append(h)
+                st = torch.cuda.ExternalStream(h.value)
+                x = torch.randn((2, 32, 32, 96), device=dev()) * (1 + i % 5)
+                torch.cuda.synchronize()
+                with torch.cuda.stream(st):
+                    y = E.conv_forward(spec, E.view_of(x), x.shape[:3], wt, b)
+                torch.cuda.synchronize()
+                ref = float(y[..., :32].abs().max())
+                assert abs(float(y._mt_amax) - ref) <= 1e-6 * ref, (i, float(y._mt_amax), ref)
+        finally:
+            torch.cuda.synchronize()
+            for h in made:
+                hip.hipStreamDestroy(h)
+
+
 def test_tiny_exit_layer_gates_by_the_saved_activation(mt):
     """conv(64 -> 128, ReLU) -> conv(128 -> 2): the backward-data of the 2-channel exit runs on the fp32 VALU
     kernel and gates by ReLU'(saved output) in its epilogue (model_dfpn.py:708-710)."""
