@@ -491,6 +491,11 @@ def run_rank(args):
         res = {'value': frames_per_step * args.steps / dt, 'unit': 'frames/s', 'ms_per_step': dt / args.steps * 1e3}
         if named and args.config == 2:
             res['step_tflops'] = TFLOP_PER_STEP[kind] * world / (res['ms_per_step'] * 1e-3)
+        if not args.no_graph:
+            # what a plain PyTorch-Lightning loop runs (__main__.py:58 trainer.fit): the same step launched eagerly
+            # from Python, no hipGraph -- same protocol (warm-up, barrier + synchronize on both sides, max over ranks)
+            dt_e = timed_steps(eager, args.steps, args.warmup, world)
+            res['eager_ms_per_step'] = dt_e / args.steps * 1e3
         if world > 1 and not args.no_graph:
             # where an N > 1 step spends its time besides forward + backward: HIP events on the launch stream around the
             # gradient exchange (it runs on the communicator's side stream; the launch stream waits for its last bucket)
@@ -554,6 +559,8 @@ def run_rank(args):
                                      '(buckets on the side stream, event-ordered) and around the Adam launch that follows the graph')
     if 'step_tflops' in head:
         out['step_tflops'] = head['step_tflops']
+    if 'eager_ms_per_step' in head:
+        out['eager_ms_per_step'] = head['eager_ms_per_step']
 
     if rank == 0:
         agg = head['_agg']

@@ -395,7 +395,9 @@ void launch_halo(const ConvK& k, hipStream_t s) {
       mt_halo_wino_launch(&k, FMT, s);
       return;
     }
-    if (KS == 5 && k.ups == 0 && halo_wino25_wanted(k.C, k.Co, 25, FMT)) {      // 1-D Winograd F(2,5), 128-wide tiles
+    // (the pack is chosen from (channels, taps, precision) alone -- mt_weight_pack_halo_frag_order -- so this test must not
+    // look at anything else: every geometry, up-sampled gathers included, goes to the kernel its pack was made for)
+    if (KS == 5 && halo_wino25_wanted(k.C, k.Co, 25, FMT)) {      // 1-D Winograd F(2,5), 128-wide tiles
       mt_halo_wino25_launch(&k, FMT, s);
       return;
     }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino25_kernel(ConvK p, int tiles
   const int ty_ = bid % tiles_y;
   const int n = bid / tiles_y;
   const int ty0 = ty_ * TH, tx0 = tx_ * TW, n0 = nty * BN;
-  const int HL = p.H, WL = p.W;
+  const int HL = p.H << p.ups, WL = p.W << p.ups;      // (ups: the input is read through a x2 nearest up-sampling)
   // the transformed image carries a further 2^-4 (|B^T d| <= 10 max|x|)
   // (bf16 planes keep fp32's exponent range and are not scaled at all)
   const float scA = FMT ? pow2_scale(*p.xamax) * 0.0625f : 1.f;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino25_kernel(ConvK p, int tiles
     const int ly = ty0 - 2 + r;
     it_ok[i] = 0;
     it_lx[i] = tx0 - 2 + 2 * t;
-    it_row[i] = (int)((long)ly * p.xsh) + 4 * c4;
+    it_row[i] = (int)((long)(ly >> p.ups) * p.xsh) + 4 * c4;
     it_dst[i] = r * ROW_E + t * ENT + 4 * c4;
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino25_kernel(ConvK p, int tiles
     for (int b = 0; b < 6; ++b) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (((it_ok[i] >> b) & 1u) && cin)
-        v = *reinterpret_cast<const f32x4*>(xin + (it_row[i] + (it_lx[i] + b) * xsw + c0));
+        v = *reinterpret_cast<const f32x4*>(xin + (it_row[i] + ((it_lx[i] + b) >> p.ups) * xsw + c0));
       d[b] = v;
     }
   };

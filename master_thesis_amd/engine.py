@@ -136,8 +136,7 @@ def _kname(template, k, co=0, ho=0, cin_p=0, ups=0):
     """Profiling label of a register-B shape: the Winograd kernels take the 3 x 3 layers
     (igemm_wino16_kernel: Cout > 64 and more than 8 output rows) and, with 128-wide tiles and whole
     32-channel chunks, the 5 x 5 ones (igemm_wino25_kernel)."""
-    if (k == 5 and HALO_WINO25 and '{rbw}' in template and ',f16' in template and co > 64 and cin_p > 32 and cin_p % 32 == 0
-            and ups == 0):
+    if k == 5 and HALO_WINO25 and '{rbw}' in template and ',f16' in template and co > 64 and cin_p > 32 and cin_p % 32 == 0:
         return 'igemm_wino25_kernel<f16>'
     if k == 3 and HALO_WINO43 and '{rbw}' in template and ',f16' in template and co > 64 and cin_p > 32:
         return 'igemm_wino43_kernel<f16>'
@@ -1049,7 +1048,10 @@ class ConvStackFn(torch.autograd.Function):
                                dx_window=sp.dx_window if i == 0 else None)
             dz = dx
             acts[i + 1] = None   # release the saved activation
-        if GRADS_READY is not None:
+        # (only when EVERY gradient of the stack was added into its flat-buffer window by the reduce launches above: a
+        # gradient that is returned instead -- MT355_INPLACE_GRADS=0, a parameter outside a FlatAdam -- is accumulated
+        # by autograd AFTER this hook, so its window is not final yet and must not go on the wire early)
+        if GRADS_READY is not None and all(g is None for g in grads):
             GRADS_READY(params)
         return (dz, None, None) + tuple(grads)
 

@@ -21,7 +21,7 @@ from . import _lib as L
 from . import engine as E
 from . import ops
 from .lightning_shim import LightningModule
-from .optim import FlatAdam
+from .optim import FlatAdam, reference_parameter_list
 from .utils import LossesUtils, take
 
 LRELU, NONE = L.ACT_LRELU, L.ACT_NONE
@@ -795,7 +795,7 @@ class CHN(LightningModule):
 
     def configure_optimizers(self):
         """model_chn.py:378-391."""
-        optimizer = FlatAdam(self.trainable_parameters(), lr=self.kwargs['lr'])
+        optimizer = FlatAdam(self.trainable_parameters(), lr=self.kwargs['lr'], all_params=reference_parameter_list(self))
         lr_scheduler = torch.optim.lr_scheduler.StepLR(
             optimizer, step_size=self.kwargs['lr_scheduler_step_size'], gamma=self.kwargs['lr_scheduler_gamma'])
         return {'optimizer': optimizer, 'lr_scheduler': lr_scheduler}

@@ -13,7 +13,7 @@ from . import _lib as L
 from . import engine as E
 from . import ops
 from .lightning_shim import LightningModule
-from .optim import FlatAdam
+from .optim import FlatAdam, reference_parameter_list
 from .utils import FlowsUtils, LossesUtils, TransformsUtils, take
 
 RELU, NONE = L.ACT_RELU, L.ACT_NONE
@@ -150,7 +150,7 @@ class DFPN(LightningModule):
     def configure_optimizers(self):
         """model_dfpn.py:295-308: Adam + StepLR; the Adam update is one fused
         kernel over a flat parameter buffer."""
-        optimizer = FlatAdam(self.trainable_parameters(), lr=self.kwargs['lr'])
+        optimizer = FlatAdam(self.trainable_parameters(), lr=self.kwargs['lr'], all_params=reference_parameter_list(self))
         lr_scheduler = torch.optim.lr_scheduler.StepLR(
             optimizer, step_size=self.kwargs['lr_scheduler_step_size'], gamma=self.kwargs['lr_scheduler_gamma'])
         return {'optimizer': optimizer, 'lr_scheduler': lr_scheduler}

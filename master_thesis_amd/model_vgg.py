@@ -29,6 +29,10 @@ def make_layers(cfg=VGG16_CFG_D):
 
 
 class VGGFeatures(nn.Module):
+    # tensors of torchvision's VGG.classifier (3 Linear layers) that the reference's VGGFeatures carries unused
+    # (model_vgg.py:11) and this one drops: optim.reference_parameter_list() keeps their places in the parameter order
+    REFERENCE_CLASSIFIER_TENSORS = 6
+
     def __init__(self, features=None, device='cpu'):
         super().__init__()
         self.features = features if features is not None else make_layers()

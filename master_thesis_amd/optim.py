@@ -9,11 +9,46 @@ from . import _lib as L
 from . import engine as E
 
 
+def reference_parameter_list(model):
+    """The list ``model.parameters()`` yields in the REFERENCE, as far as its length and order go: this package's
+    parameters in registration order (the module trees match: tests/test_abi_and_host.py), plus one placeholder per
+    tensor the reference carries and this package does not -- the six ``classifier`` tensors of torchvision's VGG
+    behind every VGGFeatures' ``features`` (model_vgg.py:11,20: the reference derives from ``torchvision.models.VGG``).
+    ``torch.optim.Adam`` numbers its state by position in this list and refuses a state dict whose group has another
+    length, so FlatAdam.state_dict() needs it to write checkpoints the reference can resume from."""
+    from .model_vgg import VGGFeatures
+    extra = {}
+    for mod in model.modules():
+        if isinstance(mod, VGGFeatures):
+            ps = list(mod.parameters())
+            if ps:
+                extra[id(ps[-1])] = VGGFeatures.REFERENCE_CLASSIFIER_TENSORS
+    out = []
+    for p in model.parameters():                   # (de-duplicated: a shared VGG appears once, where it is met first)
+        out.append(p)
+        out.extend(object() for _ in range(extra.get(id(p), 0)))
+    return out
+
+
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    """``all_params``: the parameter list the REFERENCE hands its ``torch.optim.Adam`` -- ``self.parameters()``
+    (model_dfpn.py:302, model_chn.py:385), frozen tensors included.  ``state_dict()`` numbers the optimizer state by
+    position in that list, as torch does, so that a checkpoint written here resumes in the reference."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, all_params=None):
         params = [p for p in params if p.requires_grad]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._plist = params
+        if all_params is None:
+            self._ref_index, self._ref_count = list(range(len(params))), len(params)
+        else:
+            pos = {id(p): i for i, p in enumerate(all_params)}
+            missing = [i for i, p in enumerate(params) if id(p) not in pos]
+            if missing:
+                raise ValueError(f'FlatAdam: trainable parameters {missing[:8]} are not in all_params')
+            self._ref_index, self._ref_count = [pos[id(p)] for p in params], len(pos)
+            if self._ref_index != sorted(self._ref_index):
+                raise ValueError('FlatAdam: the trainable parameters must keep the order of all_params')
         dev = params[0].device
         n = sum(p.numel() for p in params)
         self.flat_p = torch.empty((n,), device=dev, dtype=torch.float32)
@@ -123,9 +158,29 @@ class FlatAdam(torch.optim.Optimizer):
         self._dev_lr = None
         self.sync_device_lr()
 
-    def state_dict(self):
+    def flat_state_dict(self):
+        """The optimizer state as it lives here: two flat moment buffers (rounds 1-3 wrote this layout; still loadable)."""
         return {'step': self.step_count, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
                 'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+
+    def state_dict(self):
+        """The ``torch.optim.Adam`` layout (what the reference and Lightning write and read: model_dfpn.py:295-308,
+        __main__.py:33-35): ``state`` = {index in the reference's parameter list: {step, exp_avg, exp_avg_sq}} for the
+        parameters that have taken a step -- frozen tensors have an index and no entry, exactly as torch leaves them --
+        and one param group whose ``params`` runs over ALL of that list.  The moments are views of the flat buffers (a
+        checkpoint writer serialises them per parameter); ``step`` is a plain int, which torch 1.10 (the reference's pin)
+        uses as it is and current torch converts on load.  load_state_dict() takes it back."""
+        g = self.param_groups[0]
+        group = {'lr': g['lr'], 'betas': tuple(g['betas']), 'eps': g['eps'], 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None}
+        group.update({k: v for k, v in g.items() if k not in group and k != 'params'})      # (initial_lr of a scheduler, ...)
+        group['params'] = list(range(self._ref_count))
+        state = {}
+        if self.step_count > 0:
+            for idx, p, (off, k) in zip(self._ref_index, self._plist, self._slices):
+                state[idx] = {'step': int(self.step_count), 'exp_avg': self.exp_avg[off:off + k].view(p.shape),
+                              'exp_avg_sq': self.exp_avg_sq[off:off + k].view(p.shape)}
+        return {'state': state, 'param_groups': [group]}
 
     def load_state_dict(self, sd):
         """Accepts FlatAdam's own layout and the ``torch.optim.Adam`` layout of reference /
@@ -144,6 +199,9 @@ class FlatAdam(torch.optim.Optimizer):
             # checkpoint is the k-th trainable parameter here, whatever its index.
             st = sd['state']
             keys = sorted(st.keys(), key=int)
+            if len(keys) == 0:                      # (a torch optimizer that has not taken a step yet holds no state)
+                self.exp_avg.zero_()
+                self.exp_avg_sq.zero_()
             if len(keys) not in (0, len(self._plist)):
                 raise ValueError(f'optimizer state holds {len(keys)} parameters, this model trains {len(self._plist)}: '
                                  'the checkpoint was written for a different set of trainable parameters')

@@ -112,6 +112,79 @@ def test_lightning_optimizer_state_with_frozen_parameters_in_between(tmp_path):
         opt.load_state_dict(wd)
 
 
+def _reference_adam_list(model):
+    """The tensors the reference's ``torch.optim.Adam(self.parameters())`` sees for a DFPN (model_dfpn.py:302), in its
+    order, with small stand-ins for torchvision's six VGG classifier tensors; and which of them receive gradients."""
+    every, has_grad = [], []
+    for n, p in model.named_parameters():                    # (named_parameters() de-duplicates the shared VGG)
+        every.append(p)
+        has_grad.append('model_vgg' not in n)
+        if n == 'corr.model_vgg.features.28.bias':           # torchvision's VGG carries its classifier along
+            for shape in ((8, 16), (8,), (8, 8), (8,), (4, 8), (4,)):
+                every.append(torch.zeros(shape))
+                has_grad.append(False)
+    return every, has_grad
+
+
+def test_optimizer_state_written_here_resumes_in_torch_adam(tmp_path):
+    """The other direction (missing #4): ``FlatAdam.state_dict()`` IS the ``torch.optim.Adam`` layout
+    (state keyed by the reference's parameter indices, frozen tensors have an index and no state, one group over the
+    whole list), so a Lightning checkpoint written by this package resumes in the reference: a real torch Adam over
+    the reference's parameter list loads it and its next step is bit-identical to that of the torch Adam the state
+    came from.  Also: a state saved before the first step, and the flat layout of rounds 1-3, still load."""
+    import master_thesis_amd as mt
+    model = mt.DFPN(mt.VGGFeatures(), **KW)
+    model.load_state_dict(S.add_buffers(S.seeded_state_dict(S.dfpn_shapes())))
+    every, has_grad = _reference_adam_list(model)
+    from master_thesis_amd.optim import reference_parameter_list
+    assert len(reference_parameter_list(model)) == len(every)
+    origin = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in every], lr=2.5e-5)
+    g = torch.Generator().manual_seed(2)
+
+    def give_grads(opt_, seed):
+        gg = torch.Generator().manual_seed(seed)
+        for p, hg in zip(opt_.param_groups[0]['params'], has_grad):
+            p.grad = torch.randn(p.shape, generator=gg) if hg else None
+    for s_ in (10, 11, 12):
+        give_grads(origin, s_)
+        origin.step()
+    opt = model.configure_optimizers()['optimizer']
+    fresh_state = opt.state_dict()                                       # before any step: no state, as torch
+    assert fresh_state['state'] == {} and fresh_state['param_groups'][0]['params'] == list(range(len(every)))
+    opt.load_state_dict(origin.state_dict())
+    path = tmp_path / 'written_here.ckpt'
+    _lightning_file(path, model, opt.state_dict())                       # what pl.Trainer would write from this package
+    written = torch.load(path)['optimizer_states'][0]
+    want = origin.state_dict()
+    assert sorted(written['state']) == sorted(want['state']) == [i for i, hg in enumerate(has_grad) if hg]
+    assert written['param_groups'][0]['params'] == want['param_groups'][0]['params']
+    for k in ('lr', 'betas', 'eps', 'weight_decay', 'amsgrad'):
+        assert written['param_groups'][0][k] == want['param_groups'][0][k], k
+    for i, ent in want['state'].items():
+        assert int(written['state'][i]['step']) == int(ent['step']) == 3
+        assert written['state'][i]['exp_avg'].shape == ent['exp_avg'].shape
+        assert torch.equal(written['state'][i]['exp_avg'], ent['exp_avg'])
+        assert torch.equal(written['state'][i]['exp_avg_sq'], ent['exp_avg_sq'])
+    # the reference side: a torch.optim.Adam over ITS parameter list resumes from the file and steps identically
+    resumed = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in origin.param_groups[0]['params']], lr=1.0)
+    resumed.load_state_dict(written)
+    assert resumed.param_groups[0]['lr'] == 2.5e-5
+    give_grads(origin, 13)
+    give_grads(resumed, 13)
+    origin.step()
+    resumed.step()
+    for a, b in zip(origin.param_groups[0]['params'], resumed.param_groups[0]['params']):
+        assert torch.equal(a, b)
+    # a scheduler's bookkeeping travels in the group; the flat layout (rounds 1-3) still loads
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=50, gamma=0.5)
+    assert 'initial_lr' in opt.state_dict()['param_groups'][0] and sched is not None
+    opt2 = mt.DFPN(mt.VGGFeatures(), **KW).configure_optimizers()['optimizer']
+    opt2.load_state_dict(opt.flat_state_dict())
+    assert opt2.step_count == 3 and torch.equal(opt2.exp_avg, opt.exp_avg)
+    opt2.load_state_dict(fresh_state)
+    assert opt2.step_count == 0 and float(opt2.exp_avg.abs().max()) == 0.0
+
+
 def test_cpn_init_model_with_state(tmp_path):
     """model_cpn.py:93-118: the published CPN weights are a DataParallel state dict ('module.' prefix) that also
     holds CPN's own inpainting network (Encoder / CM_Module / Decoder), which this path does not use."""

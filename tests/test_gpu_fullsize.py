@@ -128,30 +128,22 @@ def _slice_batch(batch, n):
     return (cut(x), cut(m)), cut(y), tuple(cut(i) for i in info)
 
 
-@pytest.mark.parametrize('kind', ['dfpn', 'chn'])
-def test_gradients_at_benchmark_geometry(kind):
-    """The backward kernels at the geometry bench.py times, against the oracle's autograd: two clips of the
-    benchmarked batch (frames_n = 5 => R = 4 group addressing in SeparableConv4d, a 2048-image batch there,
-    256 x 256 FlowEstimator / RRDBNet layers with dx_window and the batched dense-block weight gradients at
-    trunk size), the benchmark's weights, ``training_step().backward()`` into FlatAdam's flat gradient.
-    Ground truth = the oracle in fp64 (model_dfpn.py:135-158, model_chn.py:256-280); the criterion is
-    tests/_gradcheck.py's, with the relative L2 over all parameters held to 5e-4 outright (measured, three-product
-    arithmetic: HIP 5.5e-5 / 8.2e-5 for the DFPN / CHN step, the fp32 CPU oracle itself 5.2e-5 / 8.7e-5)."""
+def _gradients_vs_fp64(kind, gbatch, cpu32=True):
+    """``training_step().backward()`` of one model on ``gbatch`` into FlatAdam's flat gradient, against the oracle's
+    autograd in fp64 (tests/_gradcheck.py).  Returns the relative L2 over all parameters (HIP, fp32 CPU oracle)."""
     sys.path.insert(0, ROOT)
     import bench
     import master_thesis_amd as mt
     from _gradcheck import check_grads_vs_fp64
-    from master_thesis_amd.synthetic import make_batch
     torch.set_num_threads(bench.host_cores())
     torch.manual_seed(0)
     vgg = mt.VGGFeatures(device=DEV)
     dfpn = mt.DFPN(vgg, **KW).to(DEV)
     model = dfpn if kind == 'dfpn' else mt.CHN(vgg, None, dfpn, **KW).to(DEV)
-    gbatch = _slice_batch(make_batch(8, 5, 256, 256, DEV, seed=1234), 2)
     opt = model.configure_optimizers()['optimizer']
     opt.zero_grad()
-    # the RRDB trunk as two launch chains, as at the full batch (two clips alone would stay below the size from which
-    # chains are used: model_chn.RRDBNetFn.CHAIN_MIN_TILES)
+    # the RRDB trunk as two launch chains, as at the full batch (a slice of it alone would stay below the size from
+    # which chains are used: model_chn.RRDBNetFn.CHAIN_MIN_TILES)
     from master_thesis_amd.model_chn import RRDBNetFn
     old_min, RRDBNetFn.CHAIN_MIN_TILES = RRDBNetFn.CHAIN_MIN_TILES, 0
     try:
@@ -168,8 +160,38 @@ def test_gradients_at_benchmark_geometry(kind):
         names = [k for k in sd if k.startswith('nn.')]
         step = O.chn_training_step
     assert len(names) == len(opt._plist)
-    tot_g, tot_c = check_grads_vs_fp64(model, step, sd, bench._cpu_batch(gbatch), names)
+    tot_g, tot_c = check_grads_vs_fp64(model, step, sd, bench._cpu_batch(gbatch), names, cpu32=cpu32)
     print(f'{kind}: relative L2 of the flat gradient vs the fp64 oracle: HIP {tot_g:.3e}, fp32 CPU oracle {tot_c:.3e}')
+    return tot_g, tot_c
+
+
+@pytest.mark.parametrize('kind', ['dfpn', 'chn'])
+def test_gradients_at_benchmark_geometry(kind):
+    """The backward kernels at the geometry bench.py times, against the oracle's autograd: two clips of the
+    benchmarked batch (frames_n = 5 => R = 4 group addressing in SeparableConv4d, a 2048-image batch there,
+    256 x 256 FlowEstimator / RRDBNet layers with dx_window and the batched dense-block weight gradients at
+    trunk size), the benchmark's weights, ``training_step().backward()`` into FlatAdam's flat gradient.
+    Ground truth = the oracle in fp64 (model_dfpn.py:135-158, model_chn.py:256-280); the criterion is
+    tests/_gradcheck.py's, with the relative L2 over all parameters held to 5e-4 outright (measured, three-product
+    arithmetic: HIP 5.5e-5 / 8.2e-5 for the DFPN / CHN step, the fp32 CPU oracle itself 5.2e-5 / 8.7e-5)."""
+    from master_thesis_amd.synthetic import make_batch
+    tot_g, tot_c = _gradients_vs_fp64(kind, _slice_batch(make_batch(8, 5, 256, 256, DEV, seed=1234), 2))
+    assert tot_g <= 5e-4, (tot_g, tot_c)
+
+
+@pytest.mark.parametrize('kind', ['dfpn', 'chn'])
+def test_gradients_at_cfg5_geometry(kind):
+    """The same check at BASELINE config 5's geometry (frames_n = 7 => R = 6, 512 x 512): one clip of the cfg-5 batch
+    (``make_batch(4, 7, 512, 512, seed=1234)``).  What only this size reaches: the RRDB trunk at 128 x 128 (1536 tiles per
+    chain half at the full batch: launch chains forced on here as the full batch would choose them, other pixel-range
+    counts of the batched weight gradients, 4-row instead of 8-row weight-gradient tiles by image height), the
+    9 -> 64 / 64 -> 3 layers and both x2 up-sampling convs at 512 x 512, the flow's 256 -> 512 bilinear resize in the
+    backward (model_dfpn.py:100-101), a 1536-image SeparableConv4d batch with R = 6 group addressing.
+    Criterion as above (model_chn.py:256-280, model_dfpn.py:135-158 in fp64) with its absolute bounds only: the fp32 run of
+    the CPU oracle is skipped here (the fp64 one alone takes two minutes at this size).  Measured: HIP 6.3e-5 (DFPN) /
+    3.9e-5 (CHN); the fp32 CPU oracle itself 1.5e-4 / 1.6e-5."""
+    from master_thesis_amd.synthetic import make_batch
+    tot_g, tot_c = _gradients_vs_fp64(kind, _slice_batch(make_batch(4, 7, 512, 512, DEV, seed=1234), 1), cpu32=False)
     assert tot_g <= 5e-4, (tot_g, tot_c)
 
 

@@ -166,6 +166,28 @@ def test_conv_forward_backward(mt, case, precision):
         assert_close(out2, y4, tol=1e-5, what='naive vs mfma')
 
 
+@pytest.mark.parametrize('case', [(5, 64, 128), (5, 128, 128), (5, 128, 64), (5, 16, 128), (3, 64, 64), (3, 128, 128),
+                                  (3, 64, 32), (3, 192, 64), (3, 8, 64)])
+def test_conv_upsampled_gather(mt, case, precision):
+    """``ups = 1``: the layer reads its input through a x2 nearest up-sampling (RRDBNet, model_chn.py:550,553: 3 x 3 layers
+    there; the entry point takes 5 x 5 ones too).  Every kernel a stride-1 layer can be dispatched to must honour it,
+    because the weight pack -- and with it the kernel -- is chosen from channels, taps and precision alone (ADVICE round
+    3: the F(2,5) pack of a 128-wide 5 x 5 layer used to reach a kernel that reads 25-tap packs when ups was set)."""
+    from master_thesis_amd import engine as E
+    k, cin, cout = case
+    n, h, w = 2, 13, 22
+    tag = 'ups.' + '.'.join(map(str, case))
+    x = S.uniform(tag + '.x', (n, cin, h, w), -1, 1)
+    wt = S.uniform(tag + '.w', (cout, cin, k, k), -0.2, 0.2)
+    bs = S.uniform(tag + '.b', (cout,), -0.5, 0.5)
+    want = F.leaky_relu(F.conv2d(F.interpolate(x, scale_factor=2, mode='nearest'), wt, bs, padding=k // 2), 0.2)
+    spec = E.LayerSpec('c', cin, cout, k, 1, 2, ups=1)
+    x4 = E.to_nhwc4(x.to(dev()))
+    y4 = E.conv_forward(spec, E.view_of(x4), x4.shape[:3], wt.to(dev()), bs.to(dev()))
+    assert y4.shape[:3] == (n, 2 * h, 2 * w)
+    assert_close(E.from_nhwc4(y4, cout), want, what='up-sampled gather')
+
+
 @pytest.mark.parametrize('case', [(2, 32, 32, 128, 128), (1, 24, 40, 64, 64), (2, 16, 16, 256, 256), (1, 19, 27, 128, 256)])
 def test_conv3x3_f16x3_is_fp32_grade(mt, case):
     """The default arithmetic on the hot 3 x 3 stride-1 layers (split fp16 operands under the 1-D Winograd
@@ -536,6 +558,74 @@ def test_warp(mt, golden):
         wgt = S.uniform(f'g2.w.{s}', (2, 3, 2, s, s), -1, 1).to(dev())
         (xa * wgt).sum().backward()
         assert_close(gg.grad, torch.from_numpy(g[f'dgrid.{s}']), tol=1e-4, what='warp dgrid')
+
+
+def _bench_flows(b, r, size, seed):
+    """The flows bench.py's warp_roofline times (random affine grids, |rotation| <= 0.2 rad, scale 1 +- 0.1, shifts of
+    up to 50 px, plus sub-pixel noise), with three kinds of hard pixels planted: grids past +-1 (the sample falls
+    outside the image on either side, up to far outside), coordinates that land EXACTLY on k + 0.5 in fp32 (the
+    nearest index is decided by the ties-to-even rule, floor by nothing) and exactly on integers / the +-1 borders."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    p = torch.rand((b * r, 4), generator=g) * 2 - 1
+    ang, sc = p[:, 0] * 0.2, 1 + p[:, 1] * 0.1
+    theta = torch.zeros((b * r, 2, 3))
+    theta[:, 0, 0], theta[:, 0, 1] = sc * torch.cos(ang), -sc * torch.sin(ang)
+    theta[:, 1, 0], theta[:, 1, 1] = sc * torch.sin(ang), sc * torch.cos(ang)
+    theta[:, :, 2] = p[:, 2:4] * (50.0 / (size / 2))
+    flow = F.affine_grid(theta, [b * r, 1, size, size], align_corners=True).reshape(b, r, size, size, 2)
+    flow = flow + (torch.rand(flow.shape, generator=g) - 0.5) * (2.0 / size)
+    # grid values whose un-normalised coordinate ((g + 1) / 2) * (size - 1) is exactly k + 0.5 / exactly k in fp32
+    k = np.arange(-2, size + 2, dtype=np.float64)
+    ties, ints = [], []
+    for frac, out in ((0.5, ties), (0.0, ints)):
+        cand = (2.0 * (k + frac) / (size - 1) - 1.0).astype(np.float32)
+        for d in (-1, 0, 1):                      # the fp32 neighbours too: keep what really evaluates to the tie
+            c = np.nextafter(cand, np.float32(np.inf if d > 0 else -np.inf)) if d else cand
+            ix = ((c + np.float32(1)) / np.float32(2)) * np.float32(size - 1)
+            out.append(c[ix == (k + frac).astype(np.float32)])
+    ties, ints = np.concatenate(ties), np.concatenate(ints)
+    assert len(ties) > size // 2 and len(ints) > size // 2
+    flat = flow.reshape(-1)
+    n = flat.numel()
+    for vals, count in ((ties, n // 50), (ints, n // 100)):
+        pos = torch.randint(0, n, (count,), generator=g)
+        flat[pos] = torch.from_numpy(vals)[torch.randint(0, len(vals), (count,), generator=g)]
+    pos = torch.randint(0, n, (n // 100,), generator=g)
+    flat[pos] = (torch.rand((n // 100,), generator=g) * 2 - 1) * 3.0          # past +-1, up to 3x the image
+    pos = torch.randint(0, n, (64,), generator=g)
+    flat[pos] = torch.tensor([1.0, -1.0, 1e30, -1e30] * 16)                        # borders and absurd values
+    return flat.reshape(b, r, size, size, 2).contiguous()
+
+
+@pytest.mark.parametrize('size', [256, 512])
+def test_warp_bit_exact_at_benchmark_sizes(mt, size):
+    """FlowsUtils.align_set (utils.py:77-104) at the sizes the bench times (256 x 256: cfg 2-4; 512 x 512: cfg 5), on the
+    kernel the bench times (warp_fwd4_kernel: whole 256-pixel wave loads), with the bench's flow distribution plus
+    planted ties / out-of-range values: the corner and nearest INDICES the kernel used equal the numpy restatement of
+    ATen's arithmetic for every pixel, and the nearest-warped map equals the oracle's grid_sample bit for bit ON THE
+    SAME FLOW (the map holds distinct random values, so an equal output means an equal source index)."""
+    from master_thesis_amd import ops
+    b, r = 2, 3
+    flow = _bench_flows(b, r, size, seed=31 + size)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    x = torch.rand((b, 3, r, size, size), generator=g)
+    v = torch.rand((b, 1, r, size, size), generator=g) + 0.25             # distinct, never 0 (0 = outside)
+    xa, va, idx = ops.align_set(x.to(dev()), v.to(dev()), flow.to(dev()), want_idx=True)
+    want = _np_warp_indices(flow, size, size)
+    got = idx.cpu().numpy().astype(np.int64)
+    # (absurd coordinates: the kernel reports INT_MIN for the corners; the restatement's int64 cast is not defined there)
+    sane = np.abs(flow.numpy()).max(axis=-1) < 1e6
+    assert sane.mean() > 0.999
+    assert np.array_equal(got[sane], want[sane]), 'corner / nearest indices differ from the restatement'
+    assert np.array_equal(got[~sane][:, 2:], np.full((int((~sane).sum()), 2), -1))
+    xo, vo = O.align_set(x, v, flow)
+    assert np.array_equal(va.cpu().numpy(), vo.numpy()), 'nearest-warped map must be bit-exact on the same flow'
+    assert float((va == 0).float().mean()) > 0.002 and float((va != 0).float().mean()) > 0.5     # both sides exercised
+    assert_close(xa, xo, tol=1e-5, what='bilinear warp')
+    # the binary visibility maps the model warps: bit-exact too
+    vb = (v > 0.6).float()
+    _, vab = ops.align_set(x.to(dev()), vb.to(dev()), flow.to(dev()))
+    assert np.array_equal(vab.cpu().numpy(), O.align_set(x, vb, flow)[1].numpy())
 
 
 def test_warp_nonsquare_and_cpn(mt, golden):

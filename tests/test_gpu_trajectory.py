@@ -1,0 +1,138 @@
+"""Training trajectories: 20 optimizer steps of the DFPN and the CHN step on one small clip (64 x 64 frames; the DFPN's
+networks still run at their fixed 256 x 256 / 64 x 64 / 16 x 16 resolutions, model_dfpn.py:74-77), four ways:
+
+* H1: HIP, weight gradients with ONE fp16 term of dY (two partial products: the default, engine.WGRAD_D_TERMS = 1),
+* H3: HIP, both terms (three partial products: fp32 grade per product),
+* H3': H3 again from initial parameters that differ by ONE fp32 rounding (every weight times 1 +- 2^-24),
+* C: the CPU oracle in fp32 with ``torch.optim.Adam`` -- what the reference trains with (model_dfpn.py:295-308,
+  model_chn.py:378-391, training_step :135-158 / :256-280).
+
+Gate of the one-term form.  What was asked for -- the one-term loss trajectory within
+1e-5 of the three-product one over 20 steps -- cannot hold for ANY two fp32 implementations of this step, the reference's
+own included, and the test shows it instead of hiding it: Adam divides by sqrt(v), so in the first steps EVERY parameter moves
+by about lr whatever the size of its gradient, and an entry whose gradient is at the rounding level moves in a direction that
+is noise; through ReLU / floor / nearest kinks the step-3 loss of two runs already differs by 1e-3 (measured, round 4:
+H3 vs C 3.4e-2 in the loss and 0.85 of the total update |theta_20 - theta_0| in the parameters after 20 DFPN steps; H1 vs C
+2.0e-2 / 0.84).  The criterion is therefore RELATIVE TO THAT SENSITIVITY, measured in the same test: (i) before the dynamics
+have amplified anything (steps 1-2) H1 = H3 to 1e-5; (ii) over the whole trajectory H1 is no further from H3 than H3 is from
+its own one-rounding twin H3' or from C (factor 2 on losses, 1.5 on parameters), and no further from C than H3 is; (iii)
+every run trains (the loss falls by a fifth).  A BIAS of the one-term gradients would show as H1 leaving the H3 / H3' / C cloud.
+"""
+import sys
+
+import pytest
+import torch
+
+import seeded as S
+from oracle import ref_torch as O
+
+pytestmark = pytest.mark.gpu
+KW = dict(lr=1e-4, lr_scheduler_step_size=50, lr_scheduler_gamma=0.5)
+DEV = 'cuda:0'
+STEPS = 20
+
+
+def _to_dev(batch):
+    (x, m), y, info = batch
+    return (x.to(DEV), m.to(DEV)), y.to(DEV), tuple(i.to(DEV) if torch.is_tensor(i) else i for i in info)
+
+
+def _hip_run(kind, sd, batch, terms, jitter=False):
+    import master_thesis_amd as mt
+    from master_thesis_amd import engine as E
+    old, E.WGRAD_D_TERMS = E.WGRAD_D_TERMS, terms
+    try:
+        vgg = mt.VGGFeatures(device=DEV)
+        dfpn = mt.DFPN(vgg, **KW)
+        chn = mt.CHN(vgg, None, dfpn, **KW)
+        chn.load_state_dict(sd)
+        chn = chn.to(DEV)
+        model = dfpn if kind == 'dfpn' else chn
+        opt = model.configure_optimizers()['optimizer']
+        if jitter:          # one fp32 rounding on every trainable weight
+            g = torch.Generator(device='cpu').manual_seed(99)
+            sign = (torch.randint(0, 2, (opt.flat_p.numel(),), generator=g).float() * 2 - 1).to(DEV)
+            opt.flat_p.mul_(1.0 + sign * 2.0 ** -24)
+            from master_thesis_amd import engine as E2
+            E2.bump_weight_epoch()
+        gbatch = _to_dev(batch)
+        losses = []
+        for _ in range(STEPS):
+            opt.zero_grad()
+            loss = model.training_step(gbatch, 0)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        names = [n for n, _ in model.named_parameters()]
+        return losses, {n: p.detach().cpu().clone() for n, p in model.named_parameters()}, names
+    finally:
+        E.WGRAD_D_TERMS = old
+
+
+def _cpu_run(kind, sd, batch, trainable):
+    """The oracle's step + torch.optim.Adam, fp32 on the host."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    if kind == 'dfpn':
+        sd = {k[len('model_aligner.'):]: v for k, v in sd.items() if k.startswith('model_aligner.')}
+        step = O.dfpn_training_step
+    else:
+        step = O.chn_training_step
+    leaves = []
+    for n in trainable:
+        sd[n] = sd[n].clone().requires_grad_(True)
+        leaves.append(sd[n])
+    opt = torch.optim.Adam(leaves, lr=KW['lr'])
+    losses = []
+    for _ in range(STEPS):
+        opt.zero_grad()
+        loss, _ = step(sd, batch)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    return losses, {n: sd[n].detach() for n in trainable}
+
+
+def _dist(a, b, ref0, names):
+    """|a - b| over |b - theta_0|, L2 over all trainable parameters."""
+    num = sum(float((a[n].double() - b[n].double()).pow(2).sum()) for n in names)
+    den = sum(float((b[n].double() - ref0[n].double()).pow(2).sum()) for n in names)
+    return (num / den) ** 0.5
+
+
+def _maxrel(a, b):
+    return max(abs(x - y) / abs(y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize('kind', ['dfpn', 'chn'])
+def test_one_term_weight_gradients_track_training(kind):
+    sys.path.insert(0, '.')
+    sd = S.add_buffers(S.seeded_state_dict(S.chn_shapes()), ('', 'model_aligner.'))
+    batch = S.synthetic_batch(1, 2, 64, 64, seed=3, flows_use=[True])
+    l3, p3, names = _hip_run(kind, sd, batch, 2)
+    l1, p1, _ = _hip_run(kind, sd, batch, 1)
+    l3j, p3j, _ = _hip_run(kind, sd, batch, 2, jitter=True)
+    if kind == 'dfpn':
+        trainable = [n for n in names if 'model_vgg' not in n]
+        key = lambda n: 'model_aligner.' + n                                     # noqa: E731
+    else:
+        trainable = [n for n in names if n.startswith('nn.')]
+        key = lambda n: n                                                        # noqa: E731
+    lc, pc = _cpu_run(kind, sd, batch, trainable)
+    theta0 = {n: sd[key(n)] for n in trainable}
+    r13, r3j, r3c, r1c = _maxrel(l1, l3), _maxrel(l3j, l3), _maxrel(l3, lc), _maxrel(l1, lc)
+    d = lambda a, b: _dist(a, b, theta0, trainable)                              # noqa: E731
+    d13, d3j, d3c, d1c = d(p1, p3), d(p3j, p3), d(p3, pc), d(p1, pc)
+    early = _maxrel(l1[:2], l3[:2])
+    fmt = lambda ls: ' '.join(f'{v:.5f}' for v in ls)                            # noqa: E731
+    print(f'{kind}: losses  C   {fmt(lc)}\n      losses  H3  {fmt(l3)}\n      losses  H1  {fmt(l1)}\n      losses  H3\' {fmt(l3j)}\n'
+          f'{kind}: max relative loss difference over {STEPS} steps: H1-H3 {r13:.2e} (steps 1-2: {early:.2e}), H3\'-H3 {r3j:.2e}, '
+          f'H3-C {r3c:.2e}, H1-C {r1c:.2e}; parameter distance in units of |theta_{STEPS} - theta_0|: H1-H3 {d13:.3e}, '
+          f'H3\'-H3 {d3j:.3e}, H3-C {d3c:.3e}, H1-C {d1c:.3e}')
+    for name, ls in (('C', lc), ('H3', l3), ('H1', l1)):
+        assert min(ls[-3:]) < 0.8 * ls[0], f'{name} must be training: {ls}'
+    assert early <= 1e-5, (early, l1[:2], l3[:2])
+    assert r13 <= 2.0 * max(r3j, r3c) + 1e-5, (r13, r3j, r3c)
+    assert r1c <= 2.0 * max(r3c, r3j) + 1e-5, (r1c, r3c)
+    assert d13 <= 1.5 * max(d3j, d3c) + 1e-3, (d13, d3j, d3c)
+    assert d1c <= 1.25 * d3c + 1e-3, (d1c, d3c)
