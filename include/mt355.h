@@ -419,7 +419,7 @@ int mt_resize_fwd(const float* src, int64_t s_plane, int64_t s_y, int64_t s_x,
                   int32_t NP, int32_t H, int32_t W, float* dst, int64_t d_plane,
                   int64_t d_y, int64_t d_x, int32_t Ho, int32_t Wo, int32_t CI,
                   int32_t mode, void* stream);
-/* backward of the bilinear mode: dsrc must be zero-filled by the caller */
+/* backward of the bilinear mode: every element of dsrc is WRITTEN (gather form, no atomics: bit-reproducible) */
 int mt_resize_bilinear_bwd(const float* ddst, int64_t d_plane, int64_t d_y,
                            int64_t d_x, int32_t NP, int32_t Ho, int32_t Wo,
                            float* dsrc, int64_t s_plane, int64_t s_y, int64_t s_x,

@@ -101,7 +101,7 @@ class ResizeFn(torch.autograd.Function):
         planes, h, w, ho, wo, ci, mode, shape = ctx.geom
         assert mode == 'bilinear', 'nearest resize is only used on no-grad tensors'
         dout = dout.contiguous()
-        dx = torch.zeros(shape, device=dout.device, dtype=torch.float32)
+        dx = torch.empty(shape, device=dout.device, dtype=torch.float32)       # (gather form: every element is written)
         L.call('mt_resize_bilinear_bwd', L.ptr(dout), ho * wo * ci, wo * ci, ci, planes, ho, wo, L.ptr(dx),
                h * w * ci, w * ci, ci, h, w, ci, L.stream_ptr())
         return dx, None, None, None
