@@ -567,13 +567,14 @@ def run_rank(args):
         tot_ms = sum(a[1] for a in agg.values())
         name, (launches, kms, kfl) = max(agg.items(), key=lambda kv: kv[1][1])
         ach = kfl / (kms * 1e-3) / 1e12
-        # MFMA products issued per fp32 multiply-add by the kernel's arithmetic
-        per = 3 if ('f16' in name or ',2,bf16' in name or name.endswith(',2>') or '_rb_' in name or 'wino' in name) else \
-            (6 if 'split' in name or 'halo' in name else 1)
-        # 1-D Winograd F(2,3) (conv_halo_wino.hip) issues 2/3 of the direct form's products (F(2,5) kernels: 6/10):
-        # its ceiling in ALGORITHMIC FLOP/s is the MFMA peak / products x that saving, and frac against THAT is the
-        # fraction of the matrix pipe's peak the executed MFMAs use (frac must not be able to pass 1)
-        saving = 2.0 if 'wino43' in name else (5.0 / 3.0 if 'wino25' in name else (1.5 if 'wino' in name else 1.0))
+        # MFMA products issued per fp32 multiply-add by the kernel's arithmetic, and the share of the direct form's products a
+        # 1-D Winograd kernel executes (F(2,3) 2/3, F(2,5) 3/5, F(4,3) 1/2): both reported by the library with the plan
+        # the launch was made from (mt_conv_plan.products / wino_num / wino_den) -- nothing is parsed out of the name.
+        # The ceiling in ALGORITHMIC FLOP/s is the MFMA peak / products / that share, and frac against THAT is the fraction
+        # of the matrix pipe's peak the executed MFMAs use (frac must not be able to pass 1)
+        from master_thesis_amd import engine as E
+        per, executed_share = E.KERNEL_INFO.get(name, (1, 1.0))        # (no entry: an fp32 VALU kernel)
+        saving = 1.0 / executed_share
         peak = PEAK_FP32_MFMA_TFLOPS if per == 1 else PEAK_16BIT_MFMA_TFLOPS / per * saving
         note = ('achieved = ALGORITHMIC conv FLOP (2*N*H*W*Cin*Cout*k*k per launch) / kernel time (HIP events around every '
                 f'launch of one eager step); peak = dense 16-bit MFMA peak {PEAK_16BIT_MFMA_TFLOPS:.0f} TFLOP/s / {per} MFMA '

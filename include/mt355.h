@@ -33,6 +33,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libmt355.so is built with -fvisibility=hidden: the declarations of this header are its whole export list. */
+#pragma GCC visibility push(default)
 
 enum mt_status {
   MT_OK = 0,
@@ -69,6 +71,7 @@ enum mt_algo { MT_ALGO_AUTO = 0, MT_ALGO_IGEMM = 1 };
  * two-term split precisions: mt_weight_pack_planes_wanted). */
 enum mt_wt_layout { MT_WT_ROWS = 0, MT_WT_HALO = 1, MT_WT_PLANES = 2 };
 
+/* ABI revision: 2 since round 4 (mt_wgrad gained d_terms in round 3 without a bump; the plan queries). */
 int mt_version(void);
 const char* mt_last_error(void);
 
@@ -154,6 +157,24 @@ int mt_conv_tiny_out_run(const mt_conv* d, const float* w, int32_t cout, int64_t
 /* slow one-thread-per-output restatement of mt_conv_run (self-check only) */
 int mt_conv_run_naive(const mt_conv* d, void* stream);
 
+/* What mt_conv_run (algo AUTO) does with a layer of this geometry and precision -- asked BEFORE packing the weights:
+ * which pack the launch must be given, which kernel family runs, and the label / arithmetic facts a profile needs.
+ * The library decides this in one place (csrc/dispatch.cpp); the host side holds no copy of the rules.
+ * Read of `d`: x.{H,W,C,sh,sw}, y.{H,C}, KH, KW, stride, pad, transposed, ups, precision, algo -- no pointer is
+ * dereferenced, nothing is launched.  cin_real / cout_real: channel counts before padding (the fp32 VALU kernels
+ * are chosen by them). */
+enum mt_conv_path { MT_PATH_IGEMM = 0, MT_PATH_HALO = 1, MT_PATH_PLANES = 2 };
+typedef struct {
+  int32_t path;          /* mt_conv_path */
+  int32_t wt_layout;     /* mt_wt_layout the launch needs: mt_weight_pack_split / _halo / _planes */
+  int32_t tiny_in_ok;    /* 1: the geometry is one mt_conv_tiny_in_run serves (no residual / accumulate on that path) */
+  int32_t tiny_out_ok;   /* 1: ... mt_conv_tiny_out_run */
+  int32_t products;      /* MFMA partial products per multiply-add of this precision: 1 (fp32), 3, 6 */
+  int32_t wino_num, wino_den;   /* executed / algorithmic products: 1/1 direct, 2/3 F(2,3), 3/5 F(2,5), 1/2 F(4,3) */
+  char kernel[96];       /* the kernel, as rocprofv3 names it (fp16 / bf16 terms spelled f16 / bf16) */
+} mt_conv_plan;
+int mt_conv_plan_query(const mt_conv* d, int32_t cin_real, int32_t cout_real, mt_conv_plan* out);
+
 /* Weight gradient (autograd of the same call-sites):
  *   dW[a][kh][kw][b] = sum_{n,y,x} D[n,y,x,a] * G[n, y*stride-pad+kh, x*..., b]
  * D is iterated densely, G is gathered (conv: D = dY, G = X;
@@ -177,13 +198,32 @@ typedef struct {
   uint32_t skip_tiles; /* halo-tile path: bit (at * btiles + bt) set = the 64 x 64 channel tile (D channels
                           64*at.., G channels 64*bt..) is not wanted and its slab entries stay undefined (a
                           launch shared by several layers forms a block-triangular product); 0 = all */
-  int32_t d_terms;     /* two-term split precisions, stride-1 3x3 / 5x5 halo-tile path: 0 / 2 = both 16-bit terms of D
+  int32_t d_terms;     /* (must be 0, 1 or 2) fp16 split, stride-1 3x3 / 5x5 producer / consumer kernel and the stride-2 gathers
+                          -- anywhere else the field is ignored (mt_wgrad_plan.d_terms tells): 0 / 2 = both 16-bit terms of D
                           (three partial products, fp32-grade); 1 = D's leading term only (two partial products: D
                           rounded to 11 / 8 significant bits, independent rounding errors per pixel, ~1e-4 relative on
                           a gradient summed over >= 10^5 pixels) -- a speed / accuracy choice of the caller */
 } mt_wgrad;
 
 int mt_wgrad_run(const mt_wgrad* d, void* stream);
+/* What mt_wgrad_run does with this geometry (read of `d`: the views' shapes and strides, KH, KW, stride, pad, ups,
+ * precision, algo, skip_tiles, d_terms; `splits` and the pointers are not looked at): the caller sizes `splits` and
+ * the slabs from it.  a_real / b_real: D's and G's channel counts before padding. */
+typedef struct {
+  int32_t halo;          /* 1: the halo-tile family takes it (with_bias available), 0: the generic gather kernels */
+  int32_t pc;            /* producer / consumer kernel: 512-thread blocks, one per CU */
+  int32_t thin;          /* 16 gathered channels: four taps per B tile, all kernel rows in one launch */
+  int32_t batchable;     /* 1: mt_wgrad_run_batch takes it */
+  int32_t tile_rows;     /* pixel tile = tile_rows x 16 */
+  int32_t ntiles;        /* pixel tiles of the whole tensor (halo family) */
+  int32_t blocks;        /* thread blocks per pixel range, summed over the launches of one call */
+  int32_t bias_tap_ok;   /* 1: with_bias may be set */
+  int32_t d_terms;       /* 16-bit terms of D that will enter: 1 only where asked for AND the kernel has the form */
+  int32_t tiny_ok;       /* 1: the geometry is one mt_wgrad_tiny_run serves (Conv2d layers only) */
+  int32_t products;      /* MFMA partial products per multiply-add */
+  char kernel[96];
+} mt_wgrad_plan;
+int mt_wgrad_plan_query(const mt_wgrad* d, int32_t a_real, int32_t b_real, mt_wgrad_plan* out);
 /* `n` weight gradients of identical geometry (everything but d.p, g.p, slabs, d_amax, g_amax) as ONE
  * grid: stride-1 3x3 layers in MT_PREC_BF16X3 / MT_PREC_F16X3 only.  Each problem has its own slabs
  * ([splits][...], reduced per problem with mt_wgrad_reduce / _multi).  For the dense blocks of the
@@ -199,7 +239,8 @@ int mt_wgrad_run_batch(const mt_wgrad* descs, int32_t n, void* stream);
 int64_t mt_wgrad_slab_floats(const mt_wgrad* d);
 /* dst[a*sa + b*sb + t*st] (+)= scale * sum_s slabs[s][a][t][b], a < A, b < B,
  * t < T; slabs are [splits][AP][TS][BP] with TS = T, or T + 1 when the launch
- * ran with_bias: then db[a] (+)= scale * sum_s slabs[s][a][T][0]. */
+ * ran with_bias: then db[a] (+)= scale * sum_s slabs[s][a][T][0].
+ * BP must be a multiple of 4 and slabs 16-byte aligned (16-byte loads). */
 int mt_wgrad_reduce(const float* slabs, int32_t splits, int32_t AP, int32_t T,
                     int32_t TS, int32_t BP, float* dst, int32_t A, int32_t B,
                     int64_t sa, int64_t sb, int64_t st, int32_t accumulate,
@@ -499,6 +540,7 @@ int mt_comm_info(void* comm, int32_t* rank, int32_t* world);
 int mt_comm_destroy(void* comm);
 int mt_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

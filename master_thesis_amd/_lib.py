@@ -38,6 +38,21 @@ class Wgrad(C.Structure):
                 ('d_amax', C.c_void_p), ('g_amax', C.c_void_p), ('skip_tiles', C.c_uint32), ('d_terms', i32)]
 
 
+class ConvPlan(C.Structure):       # mt_conv_plan
+    _fields_ = [('path', i32), ('wt_layout', i32), ('tiny_in_ok', i32), ('tiny_out_ok', i32), ('products', i32),
+                ('wino_num', i32), ('wino_den', i32), ('kernel', C.c_char * 96)]
+
+
+class WgradPlan(C.Structure):      # mt_wgrad_plan
+    _fields_ = [('halo', i32), ('pc', i32), ('thin', i32), ('batchable', i32), ('tile_rows', i32), ('ntiles', i32),
+                ('blocks', i32), ('bias_tap_ok', i32), ('d_terms', i32), ('tiny_ok', i32), ('products', i32),
+                ('kernel', C.c_char * 96)]
+
+
+PATH_IGEMM, PATH_HALO, PATH_PLANES = 0, 1, 2
+WT_ROWS, WT_HALO, WT_PLANES = 0, 1, 2
+
+
 class WarpLayout(C.Structure):
     _fields_ = [('B', i32), ('F', i32), ('C', i32), ('H', i32), ('W', i32),
                 ('xb', i64), ('xc', i64), ('xf', i64), ('vb', i64), ('vf', i64),
@@ -78,6 +93,8 @@ SIGNATURES = {
     'mt_last_error': [],
     'mt_conv_run': [_P(Conv), _vp],
     'mt_conv_run_naive': [_P(Conv), _vp],
+    'mt_conv_plan_query': [_P(Conv), i32, i32, _P(ConvPlan)],
+    'mt_wgrad_plan_query': [_P(Wgrad), i32, i32, _P(WgradPlan)],
     'mt_conv_tiny_in_run': [_P(Conv), _vp, i32, i64, i64, i64, i32, _vp],
     'mt_conv_tiny_out_run': [_P(Conv), _vp, i32, i64, i64, i64, i32, i32, i32, _vp],
     'mt_wgrad_run': [_P(Wgrad), _vp],

@@ -25,7 +25,7 @@ int mt_check_launch(const char* what) {
   return MT_OK;
 }
 
-extern "C" int mt_version(void) { return 1; }
+extern "C" int mt_version(void) { return 2; }
 extern "C" const char* mt_last_error(void) { return g_err; }
 
 // Per-stream scratch of the two-level amax reduction (common.h: AmaxScratch).  A pool of 64 zero-filled areas is

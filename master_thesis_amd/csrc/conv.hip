@@ -864,6 +864,7 @@ extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
   MT_REQUIRE(d && mt_view_ok(&d->d) && mt_view_ok(&d->g), "mt_wgrad: invalid views");
   MT_REQUIRE(d->slabs && d->splits >= 1, "mt_wgrad: slabs/splits");
   MT_REQUIRE(d->stride == 1 || d->stride == 2, "mt_wgrad: stride must be 1 or 2");
+  MT_REQUIRE(d->d_terms >= 0 && d->d_terms <= 2, "mt_wgrad: d_terms must be 0, 1 or 2 (got %d)", d->d_terms);
   MT_REQUIRE(d->d.N == d->g.N, "mt_wgrad: batch mismatch");
   const int HL = d->g.H << d->ups, WL = d->g.W << d->ups;
   MT_REQUIRE((HL + 2 * d->pad - d->KH) / d->stride + 1 == d->d.H && (WL + 2 * d->pad - d->KW) / d->stride + 1 == d->d.W,
@@ -911,6 +912,8 @@ extern "C" int mt_wgrad_reduce(const float* slabs, int32_t splits, int32_t AP, i
                                float scale, float* db, void* stream) {
   MT_REQUIRE(slabs && dst && splits >= 1 && A <= AP && B <= BP && (TS == T || TS == T + 1),
              "mt_wgrad_reduce: bad arguments");
+  // (the slabs are read with 16-byte loads at columns b .. b + 3: ADVICE round 3)
+  MT_REQUIRE((BP & 3) == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0, "mt_wgrad_reduce: BP must be a multiple of 4 and slabs 16-byte aligned");
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(mt_grid_1d((int64_t)A * TS * ((B + 3) / 4), 64, 2048)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), slabs, splits, AP, T, TS, BP, dst, A, B, (long)sa, (long)sb,
                      (long)st, accumulate, scale, db);
@@ -920,6 +923,7 @@ extern "C" int mt_wgrad_reduce(const float* slabs, int32_t splits, int32_t AP, i
 extern "C" int mt_wgrad_reduce_multi(const float* slabs, int32_t splits, int32_t AP, int32_t T, int32_t TS, int32_t BP,
                                      const mt_reduce_sub* subs, int32_t nsub, int32_t accumulate, float scale,
                                      void* stream) {
+  MT_REQUIRE((BP & 3) == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0, "mt_wgrad_reduce_multi: BP must be a multiple of 4 and slabs 16-byte aligned");
   MT_REQUIRE(slabs && subs && splits >= 1 && nsub >= 1 && nsub <= 8 && (TS == T || TS == T + 1),
              "mt_wgrad_reduce_multi: bad arguments");
   ReduceSubs rs;

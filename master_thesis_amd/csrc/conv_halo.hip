@@ -16,6 +16,7 @@
 // during the tap loop.
 #include <cstdlib>
 #include "conv_common.h"
+#include "dispatch.h"
 
 namespace {
 
@@ -346,71 +347,37 @@ __global__ __launch_bounds__(256, 2) void igemm_halo_rb_kernel(ConvK p, int tile
 }
 
 
-// The register-B kernel is used for layers with at least two K chunks (with a single chunk its
-// exposed first weight fetch costs more than the barriers it saves) and more than 32 output
-// channels (a 32-wide tile leaves a wave 6 MFMAs per tap, too few to cover the fragment fetch:
-// measured 129 vs 166 TFLOP/s for the LDS-staged kernel).  The pack routine applies the same rule.
-// MT355_HALO_RB=0 keeps the LDS-staged weight tiles everywhere (A/B switch).
-bool halo_rb_wanted(int cin_p, int cout_p) {
-  static const bool on = [] { const char* e = getenv("MT355_HALO_RB"); return !(e && e[0] == '0'); }();
-  return on && cin_p > 32 && cout_p > 32;
-}
-
-// Input channels per LDS stage of igemm_halo_kernel and of its weight tiles: 16 for the three-term split and for
-// layers whose (padded) input has at most 16 channels, else 32.  Kernel launch, pack routines and size queries
-// all go through this.
-#ifndef MT_HALO_THIN_CK
-#define MT_HALO_THIN_CK 1      // (0: 32-channel stages for every two-term layer -- A/B builds)
-#endif
-__host__ __device__ inline int halo_ck(int cin_p, int ns) { return (ns == 3 || (MT_HALO_THIN_CK && cin_p <= 16)) ? 16 : 32; }
-
 }  // namespace
-bool halo_wino_enabled();                                            // conv_halo_wino.hip
-bool halo_winox_wanted(int cin_p, int cout_p, int T);
-void mt_halo_wino_launch(const void* convk, int fmt, void* stream);
-bool halo_wino43_wanted(int cin_p, int cout_p, int T, int f16);      // conv_halo_wino43.hip
-void mt_halo_wino43_launch(const void* convk, void* stream);
+void mt_halo_wino_launch(const void* convk, int fmt, int kernel, void* stream);      // conv_halo_wino.hip (kernel: MtHaloKernel)
+void mt_halo_wino43_launch(const void* convk, void* stream);                          // conv_halo_wino43.hip
 void mt_pack_halo_wino43_launch(const float* src, int A, int B, long sa, long sb, long st, void* dst, int nchunk, int ntile,
                                 int flip, const float* wamax, int nchunk_total, int ch_off, void* stream);
-bool halo_wino25_wanted(int cin_p, int cout_p, int T, int f16);      // conv_halo_wino25.hip
-void mt_halo_wino25_launch(const void* convk, int fmt, void* stream);
+void mt_halo_wino25_launch(const void* convk, int fmt, void* stream);                 // conv_halo_wino25.hip
 void mt_pack_halo_wino25_launch(const float* src, int A, int B, long sa, long sb, long st, void* dst, int nchunk, int ntile,
                                 int flip, const float* wamax, int nchunk_total, int ch_off, void* stream);
 namespace {
-// 1-D Winograd F(2,3) on the 3 x 3 layers the register-B kernel would take (T = 9 taps)
-bool halo_wino_wanted(int cin_p, int cout_p, int T) {
-  return T == 9 && ((halo_rb_wanted(cin_p, cout_p) && halo_wino_enabled()) || halo_winox_wanted(cin_p, cout_p, T));
-}
-
+// The kernel is chosen by mt_halo_select (dispatch.cpp); this function only launches it.
 template <int KS, int NS, int FMT>
 void launch_halo(const ConvK& k, hipStream_t s) {
   const int tiles_y = (k.Ho + 7) / 8, tiles_x = (k.Wo + 15) / 16;
   const unsigned nt = (unsigned)k.N * tiles_y * tiles_x;
+  // (the xi-split kernel addresses an input image through a buffer descriptor with 32-bit offsets: images under 2 GB)
+  const bool x32 = ((long)(k.H - 1) * k.xsh + (long)(k.W - 1) * k.xsw + k.C + 4) * 4 < (1L << 31);
+  const MtHaloSel sel = mt_halo_select(KS, NS, FMT, k.C, k.Co, k.Ho, x32);
   if constexpr (NS == 2) {
-    if (KS == 3 && halo_wino43_wanted(k.C, k.Co, 9, FMT)) {      // 1-D Winograd F(4,3), 128-wide tiles, fp16 split
-      mt_halo_wino43_launch(&k, s);
-      return;
+    switch (sel.kernel) {
+      case MT_HK_WINO43: mt_halo_wino43_launch(&k, s); return;
+      case MT_HK_WINOX: case MT_HK_WINO16: case MT_HK_HALO_WINO: mt_halo_wino_launch(&k, FMT, sel.kernel, s); return;
+      case MT_HK_WINO25: mt_halo_wino25_launch(&k, FMT, s); return;
+      case MT_HK_RB:
+        if (k.Co > 64)
+          hipLaunchKernelGGL((igemm_halo_rb_kernel<KS, FMT, 1>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, tiles_y, tiles_x);
+        else
+          hipLaunchKernelGGL((igemm_halo_rb_kernel<KS, FMT, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+        return;
+      default: break;
     }
-    if (halo_wino_wanted(k.C, k.Co, KS * KS)) {
-      mt_halo_wino_launch(&k, FMT, s);
-      return;
-    }
-    // (the pack is chosen from (channels, taps, precision) alone -- mt_weight_pack_halo_frag_order -- so this test must not
-    // look at anything else: every geometry, up-sampled gathers included, goes to the kernel its pack was made for)
-    if (KS == 5 && halo_wino25_wanted(k.C, k.Co, 25, FMT)) {      // 1-D Winograd F(2,5), 128-wide tiles
-      mt_halo_wino25_launch(&k, FMT, s);
-      return;
-    }
-    if (halo_rb_wanted(k.C, k.Co)) {
-      if (k.Co > 64)
-        hipLaunchKernelGGL((igemm_halo_rb_kernel<KS, FMT, 1>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, tiles_y, tiles_x);
-      else
-        hipLaunchKernelGGL((igemm_halo_rb_kernel<KS, FMT, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
-      return;
-    }
-  }
-  if constexpr (NS == 2) {
-    if (halo_ck(k.C, NS) == 16) {          // <= 16 input channels: 16-channel stages (the packs follow: halo_ck)
+    if (sel.ck == 16) {          // <= 16 input channels: 16-channel stages (the packs follow: halo_ck)
       if (k.Co > 64)
         hipLaunchKernelGGL((igemm_halo_kernel<KS, NS, FMT, 2, 2, 2, 2, 16>), dim3(nt, (k.Co + 127) / 128), dim3(256), 0, s, k, tiles_y, tiles_x);
       else if (k.Co > 32)

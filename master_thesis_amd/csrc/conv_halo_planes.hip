@@ -17,6 +17,7 @@
 // the order the loop consumes them (mt_weight_pack_planes), so the fragment pointer only increments.
 #include <cstdlib>
 #include "conv_common.h"
+#include "dispatch.h"
 
 struct mt_plane_unit {
   long xoff;            // element offset of the unit's input view inside an image
@@ -197,20 +198,9 @@ __global__ void weight_pack_planes_kernel(const float* src, int A, int B, long s
 
 }  // namespace
 
-// MT355_PLANES=0 keeps the strided layers on the generic gather kernel (A/B switch).
-bool halo_planes_enabled() {
-  static const bool on = [] { const char* e = getenv("MT355_PLANES"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
-static bool planes_shape_ok(int K, int pad, int cin_p, int cout_p, int precision) {
-  return (K == 3 || K == 5) && pad == K / 2 && (cin_p & 31) == 0 && cin_p >= 64 && cout_p >= 64 &&
-         (precision == MT_PREC_BF16X3 || precision == MT_PREC_F16X3);
-}
-
 extern "C" int32_t mt_weight_pack_planes_wanted(int32_t AP, int32_t BP, int32_t T, int32_t precision) {
   const int K = T == 9 ? 3 : (T == 25 ? 5 : 0);
-  return (halo_planes_enabled() && K && planes_shape_ok(K, K / 2, BP, AP, precision)) ? 1 : 0;
+  return (mt_switches().planes && K && planes_shape_ok(K, K / 2, BP, AP, precision)) ? 1 : 0;
 }
 
 extern "C" int64_t mt_weight_pack_planes_elems(int32_t AP, int32_t BP, int32_t T, int32_t transposed) {
@@ -239,7 +229,7 @@ extern "C" int mt_weight_pack_planes(const float* src, int32_t A, int32_t B, int
 
 // Called by mt_conv_run: returns 1 if the launch was taken.
 int mt_halo_planes_try_launch(const mt_conv* d, void* stream) {
-  if (d->wt_layout != MT_WT_PLANES) return 0;
+  if (d->wt_layout != MT_WT_PLANES || !mt_switches().planes) return 0;
   if (d->stride != 2 || d->KH != d->KW || d->ups != 0 || !planes_shape_ok(d->KH, d->pad, d->x.C, d->y.C, d->precision)) return 0;
   if (d->precision == MT_PREC_F16X3 && (!d->x_amax || !d->w_amax)) return 0;
   ConvK k;

@@ -12,6 +12,7 @@
 #define MT_WGPC_SHADOW 1
 #endif
 #include "conv_common.h"
+#include "dispatch.h"
 
 // ------------------------------------------------------------ wgrad (halo) --
 // Weight gradient of the same stride-1 layers:
@@ -244,7 +245,6 @@ struct WgOne {};
 // rows) pay on SMALL images only: on the 16 x 16 images of SeparableConv4d the G patch of a tile shrinks from 1.5x to
 // 1.25x its pixels (5.40 -> 5.03 ms for 256 -> 256 on 8192 images), on 128^2 / 256^2 images the doubled staging registers
 // spill and the 72-element rows cost bank conflicts (1.37 -> 1.43 ms).  engine.py mirrors this rule.
-inline int wgpc_tr(int d_terms, int KS, int Hd) { return (d_terms == 1 && KS == 3 && Hd <= 16 && (Hd & 7) == 0) ? 8 : 4; }
 
 // DT = 1 (mt_wgrad.d_terms): D enters with its LEADING 16-bit term only -- two partial products (D_hi G_hi, D_hi G_lo)
 // instead of three, no D_lo plane staged or read.  D then carries 11 (fp16) significant bits: rounding errors that are
@@ -674,40 +674,13 @@ __global__ __launch_bounds__(512, 2) void wgrad_thin_kernel(WgK p, int tiles_y, 
 
 }  // namespace
 
-namespace {
-// MT355_WGRAD_PC=0: stride-1 weight gradients stay on the single-role kernel (A/B switch)
-bool wgrad_pc() {
-  static const bool on = [] { const char* e = getenv("MT355_WGRAD_PC"); return !(e && e[0] == '0'); }();
-  return on;
-}
-// MT355_WGRAD5_ROWS=1 restores one kernel row per block for the 5x5 weight gradient (A/B switch)
-// MT355_WGRAD_S2_HALO=0: stride-2 weight gradients stay on the generic kernel (A/B switch)
-bool wgrad_s2_halo() {
-  static const bool on = [] { const char* e = getenv("MT355_WGRAD_S2_HALO"); return !(e && e[0] == '0'); }();
-  return on;
-}
-// MT355_WGRAD3_TALL=0: 4-row pixel tiles for the 3x3 weight gradient (A/B switch)
-bool wgrad3_tall() {
-  static const bool on = [] { const char* e = getenv("MT355_WGRAD3_TALL"); return !(e && e[0] == '0'); }();
-  return on;
-}
-bool wgrad5_rows32() {
-  static const bool on = [] { const char* e = getenv("MT355_WGRAD5_ROWS"); return !(e && e[0] == '1'); }();
-  return on;
-}
-}  // namespace
-
 // Called by mt_wgrad_run: returns 1 if the launch was taken by the halo kernel.
 // `splits` blocks along y each own a contiguous range of pixel tiles.
 int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   const int prec = d->precision;
-  if (prec != MT_PREC_BF16X3 && prec != MT_PREC_BF16X6 && prec != MT_PREC_F16X3) return 0;
-  if ((d->stride != 1 && d->stride != 2) || d->KH != d->KW || (d->KH != 3 && d->KH != 5) || d->pad != d->KH / 2) return 0;
-  if (d->stride == 2 && (d->ups != 0 || prec == MT_PREC_BF16X6 || !wgrad_s2_halo())) return 0;
+  const MtWgradSel sel = mt_wgrad_select(d);          // (dispatch.cpp: the one place that chooses)
+  if (!sel.halo) return 0;
   if (prec == MT_PREC_F16X3 && (!d->d_amax || !d->g_amax)) return 0;
-  // 32-bit offsets inside an image (24-bit strides for v_mul_u32_u24): larger tensors take the generic kernel
-  if (!(d->d.sh < (1 << 24) && d->d.sw < (1 << 24) && d->g.sh < (1 << 24) && d->g.sw < (1 << 24) &&
-        (long)d->d.H * d->d.sh < (1L << 31) && (long)d->g.H * d->g.sh < (1L << 31))) return 0;
   WgK k;
   k.d = d->d.p; k.dsn = d->d.sn; k.dsh = d->d.sh; k.dsw = d->d.sw; k.Hd = d->d.H; k.Wd = d->d.W; k.Cd = d->d.C;
   k.g = d->g.p; k.gsn = d->g.sn; k.gsh = d->g.sh; k.gsw = d->g.sw; k.Hg = d->g.H; k.Wg = d->g.W; k.Cg = d->g.C;
@@ -718,16 +691,8 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   k.slabs = d->slabs;
   k.damax = d->d_amax; k.gamax = d->g_amax;
   k.skip = d->skip_tiles;
-  // stride 1, two-term splits: the producer / consumer kernel (4-row tiles, two LDS images)
-  // 5 x 5: kernel rows {0,1} | {2,3} | {4} in three launches (MT355_WGRAD_PC5=0: the single-role kernel, rows {0,1,2} | {3,4})
-  static const bool pc5 = [] { const char* e = getenv("MT355_WGRAD_PC5"); return !(e && e[0] == '0'); }();
-  const bool pc = d->stride == 1 && prec != MT_PREC_BF16X6 && wgrad_pc() && (d->KH == 3 || pc5);
-  // 3x3 stride 1 (two-term splits): 8-row pixel tiles (measured: +6 %; the 5x5 gradient loses 3 % with them) (twice the MFMAs per staged tile and barrier)
-  const bool tall = !pc && d->stride == 1 && d->KH == 3 && prec != MT_PREC_BF16X6 && wgrad3_tall();
-  // 16 gathered channels (and no up-sampled gather): four taps share a B tile (MT355_WGRAD_THIN=0: the kernel below)
-  static const bool thin_on = [] { const char* e = getenv("MT355_WGRAD_THIN"); return !(e && e[0] == '0'); }();
-  const bool thin = pc && thin_on && d->g.C == 16 && d->ups == 0 && !d->skip_tiles;
-  const int trows = tall ? 8 : ((pc && !thin && prec == MT_PREC_F16X3) ? wgpc_tr(d->d_terms, d->KH, k.Hd) : 4);
+  const bool pc = sel.pc, tall = sel.tall, thin = sel.thin;
+  const int trows = sel.trows, dterms = sel.d_terms;
   const int tiles_y = (k.Hd + trows - 1) / trows, tiles_x = (k.Wd + 15) / 16;
   const int ntiles = d->d.N * tiles_y * tiles_x;
   const int tps = (ntiles + d->splits - 1) / d->splits;
@@ -735,10 +700,10 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
 #define MT_WGH(KS, KHB, NS, FMT, OCC, GRID, KH_BASE) \
   hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, NS, FMT, OCC>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE)
 #define MT_WGH2(KS, KHB, FMT, GRID, KH_BASE) \
-  do { if (d->d_terms == 1) hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2, 4, 1>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE); \
+  do { if (dterms == 1) hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2, 4, 1>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE); \
        else hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE); } while (0)
 #define MT_WGPC(KS, KHB, FMT, KH_BASE) \
-  do { if (d->d_terms == 1) hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT, false, 1>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); \
+  do { if (dterms == 1) hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT, false, 1>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); \
        else hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); } while (0)
   if (thin) {
     const dim3 grid(k.atiles, d->splits);
@@ -778,7 +743,7 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
       hipLaunchKernelGGL((wgrad_halo_kernel<3, 3, 2, 1, 1, 1, 8>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0);
     else if (prec == MT_PREC_BF16X3) MT_WGH(3, 3, 2, 0, 1, grid, 0);
     else MT_WGH(3, 3, 2, 1, 1, grid, 0);
-  } else if (prec == MT_PREC_BF16X6 || !wgrad5_rows32()) {   // one kernel row (5 taps) per block
+  } else if (sel.rows5) {   // one kernel row (5 taps) per block
     dim3 grid(k.atiles * k.btiles * 5, d->splits);
     if (prec == MT_PREC_BF16X6) MT_WGH(5, 1, 3, 0, 2, grid, 0);
     else if (prec == MT_PREC_BF16X3) MT_WGH(5, 1, 2, 0, 2, grid, 0);
@@ -835,19 +800,21 @@ extern "C" int mt_wgrad_run_batch(const mt_wgrad* descs, int32_t n, void* stream
   k.M = d->d.N * d->d.H * d->d.W; k.per_split = 0;
   k.atiles = (k.Cd + 63) / 64; k.btiles = (k.Cg + 63) / 64;
   k.slabs = d->slabs; k.damax = d->d_amax; k.gamax = d->g_amax; k.skip = d->skip_tiles;
-  const int trb = prec == MT_PREC_F16X3 ? wgpc_tr(d->d_terms, 3, k.Hd) : 4;
+  const MtWgradSel sel = mt_wgrad_select(d);
+  MT_REQUIRE(sel.halo && sel.pc, "mt_wgrad_run_batch: the producer / consumer kernel does not take this layer (mt_wgrad_plan_query)");
+  const int trb = prec == MT_PREC_F16X3 ? wgpc_tr(sel.d_terms, 3, k.Hd) : 4, dterms = sel.d_terms;
   const int tiles_y = (k.Hd + trb - 1) / trb, tiles_x = (k.Wd + 15) / 16;
   const int ntiles = d->d.N * tiles_y * tiles_x;
   const int tps = (ntiles + d->splits - 1) / d->splits;
   const dim3 grid(k.atiles * k.btiles, d->splits, n);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (prec == MT_PREC_F16X3 && d->d_terms == 1 && trb == 8)
+  if (prec == MT_PREC_F16X3 && dterms == 1 && trb == 8)
     hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, true, 1, 8>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
-  else if (prec == MT_PREC_F16X3 && d->d_terms == 1)
+  else if (prec == MT_PREC_F16X3 && dterms == 1)
     hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, true, 1>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
   else if (prec == MT_PREC_F16X3)
     hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, true>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
-  else if (d->d_terms == 1)
+  else if (dterms == 1)
     hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 0, true, 1>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
   else
     hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 0, true>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);

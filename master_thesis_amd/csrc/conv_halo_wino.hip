@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "conv_common.h"
+#include "dispatch.h"
 
 namespace {
 
@@ -693,34 +694,14 @@ __global__ __launch_bounds__(512, 2) void igemm_wino16_kernel(ConvK p, int tiles
 
 }  // namespace
 
-// MT355_WINO=0 keeps the direct register-B kernel on every layer (A/B switch).
-bool halo_wino_enabled() {
-  static const bool on = [] { const char* e = getenv("MT355_WINO"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
-// MT355_WINOX=0: layers with <= 64 output channels stay on the pixel-split kernels (A/B switch, read once).
-bool halo_winox_enabled() {
-  static const bool on = [] { const char* e = getenv("MT355_WINOX"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
-// 3 x 3 layers of the xi-split kernel: more than one 32-channel K chunk's worth of gathered channels, <= 64 outputs
-bool halo_winox_wanted(int cin_p, int cout_p, int T) {
-  // (64-wide tiles from 128 gathered channels on: with two K chunks the exchange of the epilogue costs more than the
-  // halved operand traffic saves -- 0.64 vs 0.57 ms for 64 -> 64 at 256 x 256)
-  return T == 9 && halo_wino_enabled() && halo_winox_enabled() && cin_p > 32 && (cout_p <= 32 || (cout_p <= 64 && cin_p >= 128));
-}
-
-// Launch for a layer launch_halo<3, 2, FMT> sends to the Winograd path (C > 32; Co > 32, or any Co with the xi-split kernel).
-void mt_halo_wino_launch(const void* kp, int fmt, void* stream) {
+// Launch of the F(2,3) family; ``kernel`` (MtHaloKernel: MT_HK_WINOX / MT_HK_WINO16 / MT_HK_HALO_WINO) was chosen by
+// mt_halo_select (dispatch.cpp).
+void mt_halo_wino_launch(const void* kp, int fmt, int kernel, void* stream) {
   const ConvK& k = *static_cast<const ConvK*>(kp);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int tiles_y = (k.Ho + 7) / 8, tiles_x = (k.Wo + 15) / 16;
   const unsigned nt = (unsigned)k.N * tiles_y * tiles_x;
-  // (the xi-split kernel addresses an input image through a buffer descriptor with 32-bit offsets: images under 2 GB)
-  const bool x32 = ((long)(k.H - 1) * k.xsh + (long)(k.W - 1) * k.xsw + k.C + 4) * 4 < (1L << 31);
-  if (halo_winox_wanted(k.C, k.Co, 9) && x32) {
+  if (kernel == MT_HK_WINOX) {
     if (k.Co > 32) {
       if (fmt) hipLaunchKernelGGL((igemm_winox_kernel<1, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
       else hipLaunchKernelGGL((igemm_winox_kernel<0, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
@@ -730,8 +711,7 @@ void mt_halo_wino_launch(const void* kp, int fmt, void* stream) {
     }
     return;
   }
-  static const bool big = [] { const char* e = getenv("MT355_WINO16"); return !(e && e[0] == '0'); }();
-  if (k.Co > 64 && big && k.Ho > 8) {          // 16 x 16 tiles (an 8-row image would waste half of one)
+  if (kernel == MT_HK_WINO16) {          // 16 x 16 tiles, 128-wide
     const int ty16 = (k.Ho + 15) / 16;
     const unsigned nt16 = (unsigned)k.N * ty16 * tiles_x, ntn = (k.Co + 127) / 128;
     // (padded so that every XCD gets the same number of block slots: gridDim.x / ntn must be the tile count)
@@ -753,7 +733,7 @@ void mt_halo_wino_launch(const void* kp, int fmt, void* stream) {
 }
 
 #if MT_WINOX_TRACE
-extern "C" int mt_lab_winox_trace(unsigned long long* out, int n) {
+extern "C" __attribute__((visibility("default"))) int mt_lab_winox_trace(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(winox_trace), sizeof(unsigned long long) * n);
 }
 #endif

@@ -258,20 +258,6 @@ __global__ void weight_pack_halo_wino25_kernel(const float* src, int A, int B, l
 
 }  // namespace
 
-// MT355_WINO25=0 keeps the direct register-B kernel on the 5 x 5 layers (A/B switch, read once).
-bool halo_wino25_enabled() {
-  static const bool on = [] { const char* e = getenv("MT355_WINO25"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
-// 5 x 5 layers this kernel takes: 128-wide output-channel tiles, whole 32-channel K chunks on the gathered side,
-// no up-sampled gather (mt_halo_try_launch has already established stride 1, "same" padding, a two-term split)
-// fp16 split only: with the 16 significant bits of a two-term bf16 split the six-point transform is off by 5e-3 on a
-// 128-channel layer (the direct form: 1e-5), so MT_PREC_BF16X3 keeps the direct kernel.
-bool halo_wino25_wanted(int cin_p, int cout_p, int T, int f16) {
-  return T == 25 && f16 && halo_wino25_enabled() && cin_p > 32 && (cin_p & 31) == 0 && cout_p > 64;
-}
-
 void mt_halo_wino25_launch(const void* kp, int fmt, void* stream) {
   const ConvK& k = *static_cast<const ConvK*>(kp);
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -281,18 +281,6 @@ __global__ void weight_pack_halo_wino43_kernel(const float* src, int A, int B, l
 
 }  // namespace
 
-// MT355_WINO43=0 keeps F(2,3) (igemm_wino16_kernel) on the 128-wide 3 x 3 layers (A/B switch, read once).
-bool halo_wino43_enabled() {
-  static const bool on = [] { const char* e = getenv("MT355_WINO43"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
-// 3 x 3 layers this kernel takes: fp16 split, 128-wide output-channel tiles, more than one K chunk of gathered
-// channels (the decision must not depend on the image size: the weight pack is made without knowing it)
-bool halo_wino43_wanted(int cin_p, int cout_p, int T, int f16) {
-  return T == 9 && f16 && halo_wino43_enabled() && cin_p > 32 && cout_p > 64;
-}
-
 void mt_halo_wino43_launch(const void* kp, void* stream) {
   const ConvK& k = *static_cast<const ConvK*>(kp);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -313,7 +301,7 @@ void mt_pack_halo_wino43_launch(const float* src, int A, int B, long sa, long sb
 }
 
 #if MT_W43_TRACE
-extern "C" int mt_lab_w43_trace(unsigned long long* out, int n) {
+extern "C" __attribute__((visibility("default"))) int mt_lab_w43_trace(unsigned long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(w43_trace), sizeof(unsigned long long) * n);
 }
 #endif

@@ -7,6 +7,7 @@
 // that the wide tensor streams through once in 256 / 512-byte pixel rows.
 #include <cstdlib>
 #include "conv_common.h"
+#include "dispatch.h"
 
 namespace {
 
@@ -360,11 +361,6 @@ __global__ __launch_bounds__(256) void conv_tiny_out_kernel(ConvK p, const float
   finish_amax(p, vmax, sW);
 }
 
-bool tiny_enabled() {
-  static const bool on = [] { const char* e = getenv("MT355_TINY"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
 }  // namespace
 
 // w[(co) * so + (ci) * si + (tap) * st] = weight of output channel co, input channel ci, tap kh * 3 + kw of
@@ -378,7 +374,7 @@ extern "C" int mt_conv_tiny_in_run(const mt_conv* d, const float* w, int32_t cin
   ConvK k;
   const int rc = fill_convk(&e, &k);
   if (rc) return rc;
-  MT_REQUIRE(tiny_enabled(), "mt_conv_tiny_in_run: disabled (MT355_TINY=0)");
+  MT_REQUIRE(mt_switches().tiny, "mt_conv_tiny_in_run: disabled (MT355_TINY=0)");
   MT_REQUIRE(d->stride == 1 && d->KH == 3 && d->KW == 3 && d->pad == 1 && d->ups == 0 && !d->transposed,
              "mt_conv_tiny_in_run: stride-1 3x3 'same' layers only");
   MT_REQUIRE(d->x.C >= 4 && (d->y.C == 64 || d->y.C == 128), "mt_conv_tiny_in_run: x.C >= 4 and y.C in {64, 128} (got %d, %d)", d->x.C, d->y.C);
@@ -403,7 +399,7 @@ extern "C" int mt_conv_tiny_in_run(const mt_conv* d, const float* w, int32_t cin
 // mt_wgrad_run writes, so mt_wgrad_reduce / the callers' code is unchanged.  precision / amax fields are ignored.
 extern "C" int mt_wgrad_tiny_run(const mt_wgrad* d, int32_t tiny, void* stream) {
   MT_REQUIRE(d && mt_view_ok(&d->d) && mt_view_ok(&d->g) && d->slabs && d->splits >= 1, "mt_wgrad_tiny_run: invalid descriptor");
-  MT_REQUIRE(tiny_enabled(), "mt_wgrad_tiny_run: disabled (MT355_TINY=0)");
+  MT_REQUIRE(mt_switches().tiny, "mt_wgrad_tiny_run: disabled (MT355_TINY=0)");
   MT_REQUIRE(d->stride == 1 && d->KH == 3 && d->KW == 3 && d->pad == 1 && d->ups == 0, "mt_wgrad_tiny_run: stride-1 3x3 'same' layers only");
   MT_REQUIRE(d->d.N == d->g.N && d->d.H == d->g.H && d->d.W == d->g.W, "mt_wgrad_tiny_run: D and G geometry differ");
   MT_REQUIRE(tiny >= 1 && tiny <= 4, "mt_wgrad_tiny_run: 1..4 channels on the narrow side (got %d)", tiny);
@@ -446,7 +442,7 @@ extern "C" int mt_conv_tiny_out_run(const mt_conv* d, const float* w, int32_t co
   ConvK k;
   const int rc = fill_convk(&e, &k);
   if (rc) return rc;
-  MT_REQUIRE(tiny_enabled(), "mt_conv_tiny_out_run: disabled (MT355_TINY=0)");
+  MT_REQUIRE(mt_switches().tiny, "mt_conv_tiny_out_run: disabled (MT355_TINY=0)");
   MT_REQUIRE(d->stride == 1 && d->KH == d->KW && (d->KH == 3 || d->KH == 5) && d->pad == d->KH / 2 && d->ups == 0 && !d->transposed,
              "mt_conv_tiny_out_run: stride-1 3x3 / 5x5 'same' layers only");
   MT_REQUIRE(d->x.C == 128, "mt_conv_tiny_out_run: 128 input channels (got %d)", d->x.C);

@@ -81,74 +81,65 @@ class precision:
         PRECISION = self.old
 
 
-def halo_eligible(kind_fwd_like, stride, k, cin_p):
-    """Mirror of mt_halo_try_launch: non-transposed stride-1 3x3/5x5 'same'
-    layers on a split precision with >= 8-aligned input channels."""
-    return USE_HALO and PRECISION != 'f32' and kind_fwd_like and stride == 1 and k in (3, 5) and cin_p % 8 == 0
-
-
-HALO_RB = os.environ.get('MT355_HALO_RB', '1') != '0'     # mirrors halo_rb_wanted() in conv_halo.hip
-WGRAD_PC = os.environ.get('MT355_WGRAD_PC', '1') != '0'   # mirrors wgrad_pc() in conv_halo_wgrad.hip
-WGRAD_PC5 = os.environ.get('MT355_WGRAD_PC5', '1') != '0'  # 5x5 on the producer / consumer kernel too (kernel rows 2 + 2 + 1)
-WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '512'))
+WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '512'))     # blocks in flight a producer / consumer weight gradient aims at
 # 16-bit terms of dY that enter a weight gradient on the producer / consumer kernel (mt_wgrad.d_terms): 2 = both
 # (three partial products, fp32-grade per product); 1 = the leading term only (two products, default since round 3).
 # With one term dY is rounded to 11 bits PER PIXEL before it is summed over 10^5 .. 10^6 pixels: independent rounding
 # errors, 2e-4 relative on a gradient of pure noise (tests/test_gpu_kernels.py::test_weight_gradient_terms) and not
 # measurable on the training step -- flat gradient against the fp64 oracle at the benchmarked geometry 5.6e-5 / 8.2e-5
-# (DFPN / CHN) with either setting, the fp32 CPU oracle itself 5.2e-5 / 8.7e-5; four optimizer steps track the
-# three-product run to 3e-7 in the loss.  Forward and backward-DATA products always keep both terms of both operands.
+# (DFPN / CHN) with either setting, the fp32 CPU oracle itself 5.2e-5 / 8.7e-5; trajectories: tests/test_gpu_trajectory.py.
+# Forward and backward-DATA products always keep both terms of both operands.  The field is a WISH: the library applies it
+# where the kernel has the form (fp16 terms, producer / consumer and stride-2 kernels: mt_wgrad_plan.d_terms).
 WGRAD_D_TERMS = int(os.environ.get('MT355_WGRAD_D_TERMS', '1'))
-HALO_WINO = os.environ.get('MT355_WINO', '1') != '0'      # mirrors halo_wino_enabled() in conv_halo_wino.hip
-HALO_WINO25 = os.environ.get('MT355_WINO25', '1') != '0'  # mirrors halo_wino25_enabled() in conv_halo_wino25.hip
-HALO_WINOX = os.environ.get('MT355_WINOX', '1') != '0'    # mirrors halo_winox_enabled() in conv_halo_wino.hip
-HALO_WINO43 = os.environ.get('MT355_WINO43', '1') != '0'  # mirrors halo_wino43_enabled() in conv_halo_wino43.hip
-WINOX64 = 128                                             # ... 64-wide layers from 128 gathered channels on
-TINY_OUT = os.environ.get('MT355_TINY_OUT', '1') != '0'   # ... and for 128 -> 1 / 2 channel layers (A/B switch)
-TINY = os.environ.get('MT355_TINY', '1') != '0'           # fp32 VALU kernels for layers with <= 4 channels on one side (conv_tiny.hip)
+
+# ---- which kernel runs: asked from the library, never decided here ------------------------------------------------
+# Rounds 1-3 mirrored the C dispatch rules in this file.  Now the library's own
+# decision (csrc/dispatch.cpp) is queried through the ABI -- mt_conv_plan_query / mt_wgrad_plan_query -- before a weight
+# is packed or a workspace is sized, and the profiling labels are the names it reports.  Plans are cached by geometry
+# (a ctypes call per launch would cost the eager path ~2 us x 2300 launches per CHN step).
+_conv_plans, _wgrad_plans = {}, {}
+KERNEL_INFO = {}          # profiling label -> (MFMA products per multiply-add, executed / algorithmic MFMA work)
 
 
-def tiny_out_eligible(kind_c, stride, k, pad, ups, cin_real, x_cp, cout_n):
-    """mt_conv_tiny_out_run takes the layer: stride-1 3x3 / 5x5 'same', 128 gathered channels, 1 or 2 outputs."""
-    return (TINY and TINY_OUT and USE_HALO and kind_c and stride == 1 and k in (3, 5) and pad == k // 2 and ups == 0
-            and cin_real == 128 and x_cp == 128 and cout_n in (1, 2))
+def _conv_plan(d, cin_real, cout_real):
+    """(precision name, mt_conv_plan) of the launch ``d`` describes (geometry fields set).  The precision policy is
+    the host's (eff_precision: layers the halo kernels do not take may run another split), the kernel is the library's."""
+    key = (d.x.C, d.x.H, d.x.W, d.x.sh, d.x.sw, d.y.C, d.y.H, d.KH, d.stride, d.pad, d.transposed, d.ups, d.algo, PRECISION,
+           PRECISION_GENERIC, cin_real, cout_real)
+    hit = _conv_plans.get(key)
+    if hit is None:
+        d.KW = d.KH
+        d.precision = _PREC[PRECISION]
+        plan = L.ConvPlan()
+        L.call('mt_conv_plan_query', C.byref(d), cin_real, cout_real, C.byref(plan))
+        prec = eff_precision(plan.path == L.PATH_HALO)
+        if prec != PRECISION:
+            d.precision = _PREC[prec]
+            L.call('mt_conv_plan_query', C.byref(d), cin_real, cout_real, C.byref(plan))
+        name = plan.kernel.decode()
+        KERNEL_INFO[name] = (plan.products, plan.wino_num / plan.wino_den)
+        hit = _conv_plans[key] = (prec, plan, name)
+    return hit
 
 
-def tiny_in_eligible(kind_c, stride, k, pad, ups, cin_real, cout_real, x_cp):
-    """mt_conv_tiny_in_run takes the layer: stride-1 3x3 'same', <= 4 real gathered channels, 64 / 128 outputs."""
-    return (TINY and USE_HALO and kind_c and stride == 1 and k == 3 and pad == 1 and ups == 0 and 1 <= cin_real <= 4
-            and cout_real in (64, 128) and x_cp >= 4)
-
-
-def _igemm_name(co, halo, prec, cin_p=0):
-    """Name of the kernel mt_conv_run picks (profiling labels only)."""
-    cfg = '2,2,2,2' if co > 64 else ('2,2,2,1' if co > 32 else '4,1,1,1')
-    if halo and prec in ('f16x3', 'bf16x3') and cin_p > 32 and co > 32 and HALO_RB:
-        # ('{k}' == 3: the 1-D Winograd F(2,3) variant; the caller substitutes k)
-        return 'igemm_halo_{rbw}_kernel<{k},%s,%d>' % ('f16' if prec == 'f16x3' else 'bf16', 1 if co > 64 else 2)
-    if halo:
-        return 'igemm_halo_kernel<{k},%s,%s>' % (_HTAG[prec], cfg)
-    base = 'igemm_kernel' if prec == 'f32' else 'igemm_split_kernel'
-    return f'{base}<{cfg}{_KTAG[prec]}>'
-
-
-def _kname(template, k, co=0, ho=0, cin_p=0, ups=0):
-    """Profiling label of a register-B shape: the Winograd kernels take the 3 x 3 layers
-    (igemm_wino16_kernel: Cout > 64 and more than 8 output rows) and, with 128-wide tiles and whole
-    32-channel chunks, the 5 x 5 ones (igemm_wino25_kernel)."""
-    if k == 5 and HALO_WINO25 and '{rbw}' in template and ',f16' in template and co > 64 and cin_p > 32 and cin_p % 32 == 0:
-        return 'igemm_wino25_kernel<f16>'
-    if k == 3 and HALO_WINO43 and '{rbw}' in template and ',f16' in template and co > 64 and cin_p > 32:
-        return 'igemm_wino43_kernel<f16>'
-    if (k == 3 and HALO_WINO and HALO_WINOX and 'igemm_halo' in template and cin_p > 32 and '3,bf16' not in template
-            and (0 < co <= 32 or (co <= 64 and cin_p >= WINOX64))):          # the xi-split Winograd kernel (two-term splits, <= 64 output channels)
-        return 'igemm_winox_kernel<%s,%d>' % ('f16' if 'f16' in template.replace('bf16', '') else 'bf16', 2 if co > 32 else 1)
-    if k == 3 and HALO_WINO and '{rbw}' in template:
-        fmt = 'f16' if ',f16' in template else 'bf16'
-        if co > 64 and ho > 8:
-            return f'igemm_wino16_kernel<{fmt}>'
-        return f'igemm_halo_wino_kernel<{fmt},{1 if co > 64 else 2}>'
-    return template.replace('{rbw}', 'rb').replace('{k}', str(k))
+def _wgrad_plan(d, a_real, b_real):
+    """(precision name, mt_wgrad_plan, label) of the weight gradient ``d`` describes (geometry, skip_tiles, d_terms set)."""
+    key = (d.d.N, d.d.H, d.d.W, d.d.C, d.d.sh, d.d.sw, d.g.H, d.g.W, d.g.C, d.g.sh, d.g.sw, d.KH, d.stride, d.pad, d.ups,
+           d.algo, d.skip_tiles, d.d_terms, PRECISION, PRECISION_GENERIC, a_real, b_real)
+    hit = _wgrad_plans.get(key)
+    if hit is None:
+        d.KW = d.KH
+        d.precision = _PREC[PRECISION]
+        plan = L.WgradPlan()
+        L.call('mt_wgrad_plan_query', C.byref(d), a_real, b_real, C.byref(plan))
+        prec = eff_precision(bool(plan.halo))
+        if prec != PRECISION:
+            d.precision = _PREC[prec]
+            L.call('mt_wgrad_plan_query', C.byref(d), a_real, b_real, C.byref(plan))
+        name = plan.kernel.decode()
+        KERNEL_INFO[name] = (plan.products, 1.0)
+        hit = _wgrad_plans[key] = (prec, plan, name)
+    return hit
 
 
 class _Prof:
@@ -348,16 +339,6 @@ def _run_job(j):
     else:
         L.call('mt_weight_pack_split', j.src, j.A, j.B, j.T, j.sa, j.sb, j.st, j.dst, j.AP, j.BP, j.precision, j.flip,
                j.w_amax, L.stream_ptr())
-
-
-PLANES = os.environ.get('MT355_PLANES', '1') != '0'      # mirrors halo_planes_enabled() in conv_halo_planes.hip
-
-
-def planes_eligible(stride, k, cin_p, cout_p, prec, ups=0):
-    """Mirror of mt_halo_planes_try_launch: stride-2 3x3 / 5x5 layers with >= 64 channels on both
-    sides run as window convolutions over parity planes / classes on the halo-tile kernel."""
-    return (PLANES and USE_HALO and stride == 2 and k in (3, 5) and ups == 0 and prec in ('f16x3', 'bf16x3')
-            and bool(L.load().mt_weight_pack_planes_wanted(cout_p, cin_p, k * k, _PREC[prec])))
 
 
 def _pack(w, a_dim, kind, prec, flip=False, halo=False, planes=None):
@@ -576,13 +557,14 @@ def _out_amax(prec, explicit, tensor):
     return a.data_ptr(), a
 
 
-def _fill_forward_desc(d, spec, xv, w, b, out, res, alpha, beta, x_amax, y_amax, halo, prec, planes):
+def _fill_forward_desc(d, spec, xv, w, b, out, res, alpha, beta, x_amax, y_amax, plan, prec):
     """The mt_conv fields of one forward layer on the MFMA kernels (d.x / d.y are set by the caller).  Returns what
     must stay alive until the launch has been enqueued."""
     transposed = 0 if spec.kind == 'c' else 1
+    halo, planes = plan.wt_layout == L.WT_HALO, plan.wt_layout == L.WT_PLANES
     packed, wa = _pack(w, 0 if spec.kind == 'c' else 1, 'f', prec, halo=halo, planes=transposed if planes else None)
     d.wt = packed.data_ptr()
-    d.wt_layout = 2 if planes else (1 if halo else 0)
+    d.wt_layout = plan.wt_layout
     pb = _pad_bias(b, spec.cout)
     d.bias = pb.data_ptr() if pb is not None else None
     d.KH = d.KW = spec.k
@@ -611,26 +593,23 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
         out = torch.empty((n, ho, wo, cpad(spec.cout)), device=w.device, dtype=torch.float32)
     d = L.Conv()
     d.x, d.y = xv, view_of(out)
-    halo = halo_eligible(spec.kind == 'c', spec.stride, spec.k, xv.C)
-    prec = eff_precision(halo)
-    if (res is None and w.is_contiguous() and out.shape[3] == spec.cout
-            and tiny_in_eligible(spec.kind == 'c', spec.stride, spec.k, spec.pad, spec.ups, spec.cin, spec.cout, xv.C)):
+    d.KH = d.KW = spec.k
+    d.stride, d.pad, d.ups = spec.stride, spec.pad, spec.ups
+    d.transposed = 0 if spec.kind == 'c' else 1
+    d.algo = 0 if USE_HALO else 1
+    prec, plan, name = _conv_plan(d, spec.cin, spec.cout)
+    if res is None and w.is_contiguous() and plan.tiny_in_ok:
         pb = _pad_bias(b, spec.cout)
         d.bias = pb.data_ptr() if pb is not None else None
-        d.KH = d.KW = 3
-        d.stride, d.pad, d.ups, d.transposed = 1, 1, 0, 0
         d.act, d.alpha, d.beta = spec.act, alpha, 0.0
         d.res, d.dsrc = null_view(), null_view()
         d.y_amax, keep_y = _out_amax(prec, y_amax, out)
         with _Prof('conv_tiny_in_kernel', 2.0 * n * ho * wo * spec.cin * spec.cout * 9):
             L.call('mt_conv_tiny_in_run', C.byref(d), L.ptr(w), spec.cin, spec.cin * 9, 9, 1, 0, L.stream_ptr())
         return out
-    if (res is None and w.is_contiguous()
-            and tiny_out_eligible(spec.kind == 'c', spec.stride, spec.k, spec.pad, spec.ups, spec.cin, xv.C, spec.cout)):
+    if res is None and w.is_contiguous() and plan.tiny_out_ok:
         pb = _pad_bias(b, spec.cout)
         d.bias = pb.data_ptr() if pb is not None else None
-        d.KH = d.KW = spec.k
-        d.stride, d.pad, d.ups, d.transposed = 1, spec.pad, 0, 0
         d.act, d.alpha, d.beta = spec.act, alpha, 0.0
         d.res, d.dsrc = null_view(), null_view()
         d.y_amax, keep_y = _out_amax(prec, y_amax, out)
@@ -638,15 +617,11 @@ def conv_forward(spec, xv, x_shape, w, b, out=None, res=None, alpha=1.0, beta=0.
         with _Prof('conv_tiny_out_kernel', 2.0 * n * ho * wo * spec.cin * spec.cout * kk):
             L.call('mt_conv_tiny_out_run', C.byref(d), L.ptr(w), spec.cout, spec.cin * kk, kk, 1, 0, 0, 1, L.stream_ptr())
         return out
-    transposed = 0 if spec.kind == 'c' else 1
-    planes = planes_eligible(spec.stride, spec.k, xv.C, out.shape[3], prec, spec.ups)
-    keep = _fill_forward_desc(d, spec, xv, w, b, out, res, alpha, beta, x_amax, y_amax, halo, prec, planes)
+    keep = _fill_forward_desc(d, spec, xv, w, b, out, res, alpha, beta, x_amax, y_amax, plan, prec)
     if spec.kind == 'c':
         flops = 2.0 * n * ho * wo * spec.cin * spec.cout * spec.k * spec.k
     else:
         flops = 2.0 * n * h * w_ * spec.cin * spec.cout * spec.k * spec.k
-    name = f'igemm_halo_planes_kernel<{spec.k},s2,{"t" if transposed else "c"}>' if planes else \
-        _kname(_igemm_name(d.y.C, halo, prec, xv.C), spec.k, d.y.C, d.y.H, xv.C, spec.ups)
     with _Prof(name, flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
     return out
@@ -660,21 +635,26 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     d = L.Conv()
     dzv = view_of(dz)
     d.x, d.y = dzv, yv
-    # the backward-data of a stride-1 "same" Conv2d is itself a stride-1 "same"
-    # convolution with tap-flipped, channel-swapped weights: run it as a forward
-    # conv so that it takes the halo-tile kernel
-    as_fwd = halo_eligible(spec.kind == 'c', spec.stride, spec.k, dz.shape[3])
-    prec = eff_precision(as_fwd)
+    d.algo = 0 if USE_HALO else 1
+    # the backward-data of a stride-1 "same" Conv2d is itself a stride-1 "same" convolution with tap-flipped,
+    # channel-swapped weights: described as that FORWARD convolution it takes the halo-tile kernels (if the library says so)
+    fwd_like = spec.kind == 'c' and spec.stride == 1 and spec.pad == spec.k // 2
+    d.KH = d.KW = spec.k
+    d.stride, d.pad, d.ups = spec.stride, spec.pad, 0
+    d.transposed = 0 if (spec.kind != 'c' or fwd_like) else 1
+    # (gathered real channels = the conv's outputs; produced real channels = its inputs, or the wanted window of them)
+    prec, plan, name = _conv_plan(d, spec.cout, dx_window[1] if dx_window is not None else spec.cin)
+    as_fwd = fwd_like and plan.path == L.PATH_HALO
+    if fwd_like and not as_fwd:              # (no halo kernel for it: the transposed gather of the generic kernel)
+        d.transposed = 1
+        prec, plan, name = _conv_plan(d, spec.cout, spec.cin)
     if (dx_window is not None and packed is None and res is None and not accumulate and dsrc is None and w is not None
-            and w.is_contiguous()
-            and tiny_out_eligible(spec.kind == 'c', spec.stride, spec.k, spec.pad, 0, spec.cout, dzv.C, dx_window[1])):
+            and w.is_contiguous() and fwd_like and plan.tiny_out_ok):
         # only channels c0 .. c0+n-1 of the input gradient are wanted: a 128 -> n forward conv of dZ with the
         # tap-reversed kernel, written into that channel window (the rest of yv stays unwritten)
         c0, nch = dx_window
         kk = spec.k * spec.k
         d.bias = None
-        d.KH = d.KW = spec.k
-        d.stride, d.pad, d.ups, d.transposed = 1, spec.pad, 0, 0
         d.act, d.alpha, d.beta = L.ACT_NONE, alpha, 0.0
         d.res, d.dsrc = null_view(), null_view()
         d.y_amax = None
@@ -682,13 +662,13 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
             L.call('mt_conv_tiny_out_run', C.byref(d), C.c_void_p(w.data_ptr() + 4 * c0 * kk), nch, kk, spec.cin * kk, 1, 1,
                    c0, 0, L.stream_ptr())
         return
+    if dx_window is not None and fwd_like:   # (the window was only an option of the strip kernel: plan the whole gradient)
+        prec, plan, name = _conv_plan(d, spec.cout, spec.cin)
+        as_fwd = plan.path == L.PATH_HALO
     if (packed is None and res is None and not accumulate and dact_c0 == 0 and w is not None and w.is_contiguous()
-            and yv.C == spec.cin
-            and tiny_in_eligible(spec.kind == 'c', spec.stride, spec.k, spec.pad, 0, spec.cout, spec.cin, dzv.C)):
+            and fwd_like and plan.tiny_in_ok):
         # backward-data of a Conv2d with <= 4 output channels = a forward conv of dZ with the tap-reversed kernel
         d.bias = None
-        d.KH = d.KW = 3
-        d.stride, d.pad, d.ups, d.transposed = 1, 1, 0, 0
         d.act, d.alpha, d.beta = L.ACT_NONE, alpha, 0.0
         d.res = null_view()
         d.dsrc = view_of(dsrc) if dsrc is not None else null_view()
@@ -700,35 +680,24 @@ def conv_backward_data(spec, dz, w, yv, dsrc=None, dact=L.ACT_NONE, dact_c0=0, a
     if packed is not None:      # a stacked image from pack_stacked_bwd (halo-tile kernels only)
         assert as_fwd
         packed, wa = packed
-        stacked = True
     else:
-        stacked = False
-    planes = False
-    if not stacked:
-        transposed_b = 0 if (spec.kind != 'c' or as_fwd) else 1
-        planes = (not as_fwd) and planes_eligible(spec.stride, spec.k, dz.shape[3], yv.C, prec)
+        planes = plan.wt_layout == L.WT_PLANES
         packed, wa = _pack(w, 1 if spec.kind == 'c' else 0, 'bflip' if as_fwd else 'b', prec, flip=as_fwd, halo=as_fwd,
-                           planes=transposed_b if planes else None)
+                           planes=d.transposed if planes else None)
     d.wt = packed.data_ptr()
-    d.wt_layout = 2 if planes else (1 if as_fwd else 0)
+    d.wt_layout = plan.wt_layout
     d.bias = None
-    d.KH = d.KW = spec.k
-    d.stride, d.pad, d.ups = spec.stride, spec.pad, 0
-    d.transposed = 0 if (spec.kind != 'c' or as_fwd) else 1
     d.act, d.alpha = L.ACT_NONE, alpha
     d.res, d.beta = (view_of(res), beta) if res is not None else (null_view(), 0.0)
     d.dsrc = view_of(dsrc) if dsrc is not None else null_view()
     d.dact, d.dact_c0 = dact, dact_c0
     d.accumulate = 1 if accumulate else 0
     d.precision = _PREC[prec]
-    d.algo = 0 if USE_HALO else 1
     d.x_amax, keep = _amax_ptr(prec, dz_amax, dzv)
     d.w_amax = wa.data_ptr() if wa is not None else None
     d.y_amax, keep_y = _out_amax(prec, y_amax, yv._src)
     side = d.x if spec.kind == 'c' else yv          # the conv's output side
     flops = 2.0 * side.N * side.H * side.W * spec.cin * spec.cout * spec.k * spec.k
-    name = f'igemm_halo_planes_kernel<{spec.k},s2,{"t" if d.transposed else "c"}>' if planes else \
-        _kname(_igemm_name(yv.C, as_fwd, prec, dzv.C), spec.k, yv.C, yv.H, dzv.C)
     with _Prof(name, flops):
         L.call('mt_conv_run', C.byref(d), L.stream_ptr())
 
@@ -809,6 +778,7 @@ class WgradBatch:
                     it[1].splits = splits
                     it[1].slabs = slabs.data_ptr() + 4 * i * splits * per
                     C.memmove(C.byref(arr, i * C.sizeof(L.Wgrad)), C.byref(it[1]), C.sizeof(L.Wgrad))
+                KERNEL_INFO[kname + f' x{n}'] = KERNEL_INFO.get(kname, (3, 1.0))
                 with _Prof(kname + f' x{n}', sum(it[8] for it in chunk)):
                     L.call('mt_wgrad_run_batch', arr, n, L.stream_ptr())
                 for i, it in enumerate(chunk):
@@ -841,54 +811,15 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
         dv, gv, a, b = xin_view, dzv, spec.cin, spec.cout
         da, ga = x_amax, dz_amax
     ap, bp, t = cpad(a), cpad(b), spec.k * spec.k
-    # tiles as chosen by wgrad_cfg in conv.hip
-    if ap > 64 and bp > 64:
-        tiles, wcfg = ((ap + 127) // 128) * ((bp + 127) // 128), '2,2,2,2'
-    elif ap <= 32:
-        tiles, wcfg = (bp + 127) // 128, '1,4,1,1'
-    elif bp <= 32:
-        tiles, wcfg = (ap + 127) // 128, '4,1,1,1'
-    else:
-        tiles, wcfg = ((ap + 63) // 64) * ((bp + 63) // 64), '2,2,1,1'
     pixels = dv.N * dv.H * dv.W
     d = L.Wgrad()
     d.d, d.g = dv, gv
     d.KH = d.KW = spec.k
     d.stride, d.pad = spec.stride, spec.pad
     d.ups = spec.ups if spec.kind == 'c' else 0
-    halo = USE_HALO and PRECISION != 'f32' and spec.stride == 1 and spec.k in (3, 5)
-    if (USE_HALO and spec.stride == 2 and spec.k in (3, 5) and d.ups == 0 and eff_precision(True) in ('f16x3', 'bf16x3')
-            and os.environ.get('MT355_WGRAD_S2_HALO', '1') != '0'):
-        halo = True        # stride-2 gathers (strided convs, transposed convs) on the halo-tile kernel too
-    prec = eff_precision(halo)
-    if halo:   # wgrad_halo_kernel: 64 x 64 channel tiles, all taps (3x3) or one kernel row (5x5) per block
-        # 3x3: all taps in one block; 5x5: kernel rows {0,1,2} | {3,4} in two launches (bf16x6 and
-        # MT355_WGRAD5_ROWS=1: five one-row blocks) -- mirrors mt_wgrad_halo_try_launch
-        rows5 = prec == 'bf16x6' or os.environ.get('MT355_WGRAD5_ROWS', '0') == '1'
-        blocks = ((ap + 63) // 64) * ((bp + 63) // 64) * (1 if spec.k == 3 else (5 if rows5 else 2))
-        # stride 1, two-term splits: the producer / consumer kernel (4-row tiles, 512-thread blocks, one per CU)
-        pc = spec.stride == 1 and prec != 'bf16x6' and WGRAD_PC and (spec.k == 3 or WGRAD_PC5)
-        if pc:
-            blocks = ((ap + 63) // 64) * ((bp + 63) // 64)       # (5 x 5: three launches of that many blocks x splits)
-        # pixel tiles of 8 x 16 for the single-role 3x3 stride-1 gradient, 4 x 16 otherwise (as mt_wgrad_halo_try_launch)
-        trows = 8 if (not pc and spec.k == 3 and spec.stride == 1 and prec != 'bf16x6'
-                      and os.environ.get('MT355_WGRAD3_TALL', '1') != '0') else 4
-        if (pc and WGRAD_D_TERMS == 1 and prec == 'f16x3' and spec.k == 3 and dv.H <= 16 and dv.H % 8 == 0
-                and not (bp == 16 and d.ups == 0 and sub_blocks is None and os.environ.get('MT355_WGRAD_THIN', '1') != '0')):
-            trows = 8          # mirrors wgpc_tr() in conv_halo_wgrad.hip: 8-row tiles on small images (one term of D)
-        ntiles = dv.N * ((dv.H + trows - 1) // trows) * ((dv.W + 15) // 16)
-        want = WGRAD_PC_BLOCKS if pc else 512        # blocks in flight: one 512-thread block per CU for pc
-        # (fp16 terms only: the leading bf16 term has 8 bits -- 1.3e-3 on a noise gradient; the stride-2 gathers of the
-        # single-role kernel take the option too)
-        d.d_terms = WGRAD_D_TERMS if ((pc or spec.stride == 2) and prec == 'f16x3') else 0
-        d.splits = max(1, min((want + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 256))
-    else:
-        d.splits = _splits(tiles * t, pixels)
     d.algo = 0 if USE_HALO else 1
-    # on the halo path the bias gradient rides along as one more slab "tap"
-    fused_bias = halo and need_bias and spec.kind == 'c'
-    d.with_bias = 1 if fused_bias else 0
-    if sub_blocks is not None and halo:
+    d.d_terms = WGRAD_D_TERMS        # (a wish: the library applies it where the kernel has the one-term form)
+    if sub_blocks is not None:
         # block-triangular product: 64 x 64 tiles (a-tile, b-tile) that no sub-block reads are skipped
         nbt = (bp + 63) // 64
         need = set()
@@ -897,25 +828,28 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
                 for bt_ in range(0, (sb[2] - 1) // 64 + 1):
                     need.add(at_ * nbt + bt_)
         d.skip_tiles = sum(1 << i for i in range(min(32, ((ap + 63) // 64) * nbt)) if i not in need)
+    # which kernel, how many blocks per pixel range, how many pixel tiles: the library's answer (csrc/dispatch.cpp)
+    prec, plan, kname = _wgrad_plan(d, a, b)
+    halo, pc = bool(plan.halo), bool(plan.pc)
+    blocks, ntiles = plan.blocks, plan.ntiles
+    if halo:
+        want = WGRAD_PC_BLOCKS if pc else 512        # blocks in flight: one 512-thread block per CU for pc
+        d.splits = max(1, min((want + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 256))
+    else:
+        d.skip_tiles = 0
+        d.splits = _splits(blocks, pixels)
+    # on the halo path the bias gradient rides along as one more slab "tap"
+    fused_bias = bool(plan.bias_tap_ok) and need_bias and spec.kind == 'c'
+    d.with_bias = 1 if fused_bias else 0
     ts = t + (1 if fused_bias else 0)
     d.precision = _PREC[prec]
     d.d_amax, keep1 = _amax_ptr(prec, da, dv)
     d.g_amax, keep2 = _amax_ptr(prec, ga, gv)
-    if halo:
-        thin = pc and bp == 16 and d.ups == 0 and sub_blocks is None and os.environ.get('MT355_WGRAD_THIN', '1') != '0'
-        kname = f'wgrad_thin_kernel<{spec.k},{"f16" if prec == "f16x3" else "bf16"}>' if thin else \
-                (f'wgrad_pc_kernel<{spec.k},{3 if spec.k == 3 else "2+2+1"},{"f16" if prec == "f16x3" else "bf16"}>' if pc else
-                 f'wgrad_halo_kernel<{spec.k},{3 if spec.k == 3 else (1 if rows5 else "3+2")},{_HTAG[prec]}>')
-    else:
-        kname = ('wgrad_kernel' if prec == 'f32' else 'wgrad_split_kernel') + f'<{wcfg}{_KTAG[prec]}>'
     useful = spec.cin * spec.cout if sub_blocks is None else sum(sb[1] * sb[2] for sb in sub_blocks)
     flops = 2.0 * pixels * useful * t                 # (algorithmic FLOP: only the sub-blocks that are kept)
-    batchable = (defer is not None and halo and pc and spec.k == 3 and d.ups == 0 and prec in ('f16x3', 'bf16x3')
-                 and dv.H == gv.H and dv.W == gv.W)
+    batchable = defer is not None and bool(plan.batchable)
     # <= 4 real channels on one side, 64 / 128 on the other, stride-1 3x3: the fp32 VALU kernel (conv_tiny.hip)
-    tiny_w = (TINY and halo and spec.kind == 'c' and spec.stride == 1 and spec.k == 3 and spec.pad == 1 and d.ups == 0
-              and sub_blocks is None and min(spec.cin, spec.cout) <= 4 and max(spec.cin, spec.cout) in (64, 128)
-              and max(ap, bp) == max(spec.cin, spec.cout) and dv.H == gv.H and dv.W == gv.W)
+    tiny_w = bool(plan.tiny_ok) and spec.kind == 'c' and sub_blocks is None
     if tiny_w:
         rows = 8 if max(ap, bp) == 128 else 16
         nt_ = dv.N * ((dv.H + rows - 1) // rows) * ((dv.W + 15) // 16)

@@ -18,11 +18,15 @@ parameters; H3 vs C32 2.5e-2 / 0.84; H1 vs H3 2.0e-2 / 0.79.  On the CHN step th
 gradient at this clip is off by 1e-2 per tensor against fp64 (kink flips at 16 x 16 trunk resolution; HIP: 5e-4), its first
 Adam update deviates from the fp64 one by 0.0065 lr on average (HIP, one or two terms alike: 0.0002;
 scratch/r4_traj_diag.py), and from step 2 on it descends along another path (loss 5.897 against 5.685 at step 3).
-The criterion is therefore RELATIVE TO THAT SENSITIVITY, with the fp64 trajectory as the yardstick:
+The criterion is therefore RELATIVE TO THAT SENSITIVITY, against a yardstick trajectory Y (CHN: C64; DFPN: C32 -- twenty
+fp64 DFPN steps are three minutes of CPU and were run once, gpurun_out/r4e_traj.log: H3 / H1 / H3' / C32 sit 7.7e-2 / 7.3e-2 /
+8.3e-2 / 6.4e-2 in the loss and 0.85 / 0.84 / 0.86 / 0.80 in the parameters from C64, one cloud):
 (i) before the dynamics have amplified anything (steps 1-2) H1 = H3 to 2e-5;
-(ii) over the whole trajectory H1 stays as close to C64 -- in the loss and in the parameters -- as the better-off of H3 and
-     C32 does (factor 1.25), i.e. the one-term form trains no worse than the reference's own fp32 arithmetic;
-(iii) every run trains (the loss falls).  A BIAS of the one-term gradients would show as H1 leaving the H3 / H3' / C32 cloud.
+(ii) over the whole trajectory H1 stays as close to Y as the other members of the cloud do (H3, H3', and C32 where Y is
+     C64): within a factor 2 of the worst of them in the loss (a maximum over 20 chaotic steps moves by that much from run
+     to run) and 1.25 in the parameters -- i.e. the one-term form trains no worse than the reference's own fp32 arithmetic;
+(iii) every run trains (the loss falls).  A BIAS of the one-term gradients would show as H1 leaving the cloud.
+Measured on the CHN step: loss H3 4.2e-2, H1 2.4e-2, C32 4.7e-2; parameters H3 0.55, H1 0.67, C32 1.01 from C64.
 """
 import sys
 
@@ -128,23 +132,28 @@ def test_one_term_weight_gradients_track_training(kind):
         trainable = [n for n in names if n.startswith('nn.')]
         key = lambda n: n                                                        # noqa: E731
     lc, pc = _cpu_run(kind, sd, batch, trainable)
-    l64, p64 = _cpu_run(kind, sd, batch, trainable, torch.float64)
     theta0 = {n: sd[key(n)] for n in trainable}
     d = lambda a, b: _dist(a, b, theta0, trainable)                              # noqa: E731
-    runs = {'H3': (l3, p3), 'H1': (l1, p1), "H3'": (l3j, p3j), 'C32': (lc, pc)}
-    r64 = {k: _maxrel(v[0], l64) for k, v in runs.items()}
-    d64 = {k: d(v[1], p64) for k, v in runs.items()}
+    runs = {'H3': (l3, p3), 'H1': (l1, p1), "H3'": (l3j, p3j)}
+    if kind == 'chn':
+        yname, (ly, py) = 'C64', _cpu_run(kind, sd, batch, trainable, torch.float64)
+        runs['C32'] = (lc, pc)
+    else:
+        yname, (ly, py) = 'C32', (lc, pc)
+    ry = {k: _maxrel(v[0], ly) for k, v in runs.items()}
+    dy = {k: d(v[1], py) for k, v in runs.items()}
     early = _maxrel(l1[:2], l3[:2])
     fmt = lambda ls: ' '.join(f'{v:.5f}' for v in ls)                            # noqa: E731
-    print(f'{kind}: losses C64 {fmt(l64)}')
+    print(f'{kind}: losses {yname} {fmt(ly)}')
     for k, v in runs.items():
         print(f'      losses {k:3s} {fmt(v[0])}')
-    print(f'{kind}: max relative loss difference to C64 over {STEPS} steps: ' + ', '.join(f'{k} {v:.2e}' for k, v in r64.items()) +
+    print(f'{kind}: max relative loss difference to {yname} over {STEPS} steps: ' + ', '.join(f'{k} {v:.2e}' for k, v in ry.items()) +
           f'; H1-H3 {_maxrel(l1, l3):.2e} (steps 1-2: {early:.2e}), H3\'-H3 {_maxrel(l3j, l3):.2e}')
-    print(f'{kind}: parameter distance to C64 in units of |theta_{STEPS} - theta_0|: ' + ', '.join(f'{k} {v:.3e}' for k, v in d64.items()) +
+    print(f'{kind}: parameter distance to {yname} in units of |theta_{STEPS} - theta_0|: ' + ', '.join(f'{k} {v:.3e}' for k, v in dy.items()) +
           f'; H1-H3 {d(p1, p3):.3e}, H3\'-H3 {d(p3j, p3):.3e}')
-    for name, ls in [('C64', l64)] + [(k, v[0]) for k, v in runs.items()]:
+    for name, ls in [(yname, ly)] + [(k, v[0]) for k, v in runs.items()]:
         assert min(ls[-3:]) < 0.95 * ls[0], f'{name} must be training: {ls}'
     assert early <= 2e-5, (early, l1[:2], l3[:2])
-    assert r64['H1'] <= 1.25 * max(r64['H3'], r64['C32']) + 1e-4, r64
-    assert d64['H1'] <= 1.25 * max(d64['H3'], d64['C32']) + 1e-3, d64
+    cloud = [k for k in runs if k != 'H1']
+    assert ry['H1'] <= 2.0 * max(ry[k] for k in cloud) + 1e-4, ry
+    assert dy['H1'] <= 1.25 * max(dy[k] for k in cloud) + 1e-3, dy
