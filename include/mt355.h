@@ -12,7 +12,7 @@
  *   - return 0 on success, a negative mt_status otherwise; no exceptions cross
  *     the ABI; mt_last_error() gives a thread-local message.
  *   - nothing synchronises, and the caller passes workspaces; the one allocation inside the library is a 4 MB pool of
- *     reduction scratch (one area per stream), made by the first launch outside a graph capture.
+ *     reduction scratch (one area per stream), made by mt_init().
  *   - activations inside the engine are "NHWC" engine tensors: float32,
  *     channels innermost and contiguous, the channel count padded with ZEROS.
  *     The ABI itself accepts any C % 4 == 0 (mt_view); the LDS halo-tile
@@ -74,6 +74,12 @@ enum mt_wt_layout { MT_WT_ROWS = 0, MT_WT_HALO = 1, MT_WT_PLANES = 2 };
 /* ABI revision: 2 since round 4 (mt_wgrad gained d_terms in round 3 without a bump; the plan queries). */
 int mt_version(void);
 const char* mt_last_error(void);
+/* Allocates the library's one piece of device memory -- a 4 MB pool of reduction scratch, one area per stream (two-level
+ * max|y| of the conv epilogues, fixed-order loss sums) -- on the current device.  Call it once after the device is chosen
+ * and outside any graph capture; a launch that finds no pool falls back to allocating it itself (outside captures) or to
+ * same-address atomics.  mt_amax_scratch_reset re-zeroes the pool on `stream` (after an aborted launch; not capturable). */
+int mt_init(void);
+int mt_amax_scratch_reset(void* stream);
 
 /* A strided NHWC4 view: element (n, y, x, c) lives at
  * p[(n / n_in)*sg + (n % n_in)*sn + y*sh + x*sw + c], c < C (C % 4 == 0,

@@ -91,6 +91,8 @@ _vp = C.c_void_p
 SIGNATURES = {
     'mt_version': [],
     'mt_last_error': [],
+    'mt_init': [],
+    'mt_amax_scratch_reset': [_vp],
     'mt_conv_run': [_P(Conv), _vp],
     'mt_conv_run_naive': [_P(Conv), _vp],
     'mt_conv_plan_query': [_P(Conv), i32, i32, _P(ConvPlan)],
@@ -171,6 +173,13 @@ def load():
         fn.argtypes = args
         fn.restype = _RESTYPES.get(name, C.c_int)
     _lib = lib
+    if torch.cuda.is_available():
+        # the library's one device allocation (reduction scratch), made here -- eagerly, outside any graph capture --
+        # instead of inside the first launch
+        with torch.cuda.device(torch.cuda.current_device()):
+            rc = lib.mt_init()
+        if rc != 0:
+            raise MT355Error(f'mt_init failed ({rc}): {lib.mt_last_error().decode()}')
     return lib
 
 

@@ -40,6 +40,13 @@ __device__ unsigned long long w43_trace[8192 * 8];
 #define W43_STAMP(i) do {} while (0)
 #endif
 
+#ifndef MT_W43_PREFETCH
+#define MT_W43_PREFETCH 0            // (1: lab build with the successor's L2 prefetch -- measured and rejected, see below)
+#endif
+#ifndef MT_W43_PREFETCH_AHEAD
+#define MT_W43_PREFETCH_AHEAD 32     // blocks of one XCD in flight: 32 CUs x one block
+#endif
+
 template <int FMT>
 __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles_y, int tiles_x) {
   constexpr int NS = 2, CK = 32, TH = 16, TW = 16, BN = 128, TM = 2, NXI = 6;
@@ -212,6 +219,32 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
   }
 
   W43_STAMP(2);
+#if MT_W43_PREFETCH
+  // ---- L2 prefetch for the block that takes this CU next (round 4) -----------------------------------------------------
+  // One 512-thread block per CU and 32 CUs per XCD: the block that starts when this one retires is, to a good
+  // approximation, lid + 32 of the same XCD -- the same L2.  Its prologue waits for the first chunk of its halo with
+  // nothing to overlap (4.9 of a block's 38 us): touch that chunk now (one dword per pixel = per
+  // 128-byte line), so that the loads of its prologue are L2 hits.  The value is consumed after the last store.
+  // MEASURED AND REJECTED (round 4, alternating builds on one box, scratch/r4_pf43.sh): igemm_wino43_kernel per DFPN step
+  // 33.17 / 33.32 ms without, 33.91 / 33.82 ms with (32 ahead), 33.65 (64 ahead), 33.45 (16 ahead): the prologue's latency is
+  // not an L2-miss latency -- the touch only adds traffic in front of the stores.  Off by default.
+  float pf_touch = 0.f;
+  {
+    const int q8 = npt >> 3, r8 = npt & 7;
+    const int mine = q8 + (xcd < r8 ? 1 : 0), start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int tl2 = (lid + MT_W43_PREFETCH_AHEAD) / ntn;
+    const int r = tid / 22, c = tid - r * 22;
+    if (tl2 < mine && tl2 != lid / ntn && r < ROWS) {
+      int b2 = start + tl2;
+      const int tx2 = b2 % tiles_x; b2 /= tiles_x;
+      const int ty2 = b2 % tiles_y;
+      const int n2 = b2 / tiles_y;
+      const int ly = ty2 * TH - 1 + r, lx = tx2 * TW - 1 + c;
+      if ((unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL)
+        pf_touch = p.x[(long)(n2 / p.xni) * p.xsg + (long)(n2 % p.xni) * p.xsn + (long)(ly >> p.ups) * p.xsh + (long)(lx >> p.ups) * p.xsw];
+    }
+  }
+#endif
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // Output transform  y0 = m0 + m1 + m2 + m3 + m4,  y1 = m1 - m2 + 2 m3 - 2 m4,  y2 = m1 + m2 + 4 m3 + 4 m4,
   // y3 = m1 - m2 + 8 m3 - 8 m4 + m5.  xi half 0 holds m0 m1 m2, half 1 m3 m4 m5: each reduces them to its shares of
@@ -271,6 +304,9 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
   W43_STAMP(4);
   finish_amax(p, vmax, sV);
   W43_STAMP(5);
+#if MT_W43_PREFETCH
+  if (pf_touch == 1.2345e-30f) p.y[0] = pf_touch;       // (never true for real data: keeps the touch alive)
+#endif
 }
 
 __global__ void weight_pack_halo_wino43_kernel(const float* src, int A, int B, long sa, long sb, long st, __bf16* dst,

@@ -321,6 +321,25 @@ def test_output_amax_scalars(mt, case):
             assert float(a) == float(y.abs().max())
 
 
+def test_amax_scratch_is_made_at_load_and_can_be_reset(mt):
+    """the reduction scratch is allocated by mt_init() when the library is loaded (not lazily inside a
+    launch, where it could break another stream's graph capture), and mt_amax_scratch_reset() re-zeroes it: the
+    reductions are exact right after a reset, also inside a graph captured straight away."""
+    from master_thesis_amd import _lib as L
+    from master_thesis_amd import engine as E
+    assert L.load().mt_init() == 0                       # idempotent
+    L.call('mt_amax_scratch_reset', L.stream_ptr())
+    y = torch.randn((3, 20, 28, 64), device=dev())
+    assert float(E.absmax_into(y, E.new_amax(y.device))) == float(y.abs().max())
+    a = E.new_amax(y.device)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        E.absmax_into(y, a)
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(a) == float(y.abs().max())
+
+
 def test_output_amax_on_concurrent_streams_and_past_the_scratch_pool(mt):
     """The two-level reduction keeps its slots in a per-stream scratch (64 areas): launches on different streams run
     side by side without sharing one, and a stream past the pool falls back to the filtered atomic -- the scalar is
