@@ -74,6 +74,7 @@ def _rank(rank, world, port, backend, out, inplace=True):
     model.load_state_dict(sd)
     model = model.to(dev)
     opt = model.configure_optimizers()['optimizer']
+    mdist.init_comm(dev)             # the transport bootstrap is a collective of its own: done here, by all ranks together
     mdist.broadcast_parameters(opt)                                         # ... and agree after the broadcast
     (x, m), y, info = S.synthetic_batch(2, 2, 64, 64, seed=31)             # clip r belongs to rank r
     sl = slice(rank, rank + 1)
@@ -161,6 +162,7 @@ def _rank_graphed(rank, world, port, out, steps):
     model.load_state_dict(S.add_buffers(S.seeded_state_dict(S.dfpn_shapes(), seed=rank)))       # ranks start apart ...
     model = model.to(dev)
     opt = model.configure_optimizers()['optimizer']
+    mdist.init_comm(dev)
     mdist.broadcast_parameters(opt)                                                             # ... and agree after this
     (x, m), y, info = S.synthetic_batch(world, 2, 64, 64, seed=31)                             # clip r belongs to rank r
     sl = slice(rank, rank + 1)
