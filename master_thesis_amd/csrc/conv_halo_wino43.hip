@@ -43,6 +43,9 @@ __device__ unsigned long long w43_trace[8192 * 8];
 #ifndef MT_W43_PREFETCH
 #define MT_W43_PREFETCH 0            // (1: lab build with the successor's L2 prefetch -- measured and rejected, see below)
 #endif
+#ifndef MT_W43_SKIP_R1
+#define MT_W43_SKIP_R1 1              // (0: A/B builds that always run the second transform round)
+#endif
 #ifndef MT_W43_PREFETCH_AHEAD
 #define MT_W43_PREFETCH_AHEAD 32     // blocks of one XCD in flight: 32 CUs x one block
 #endif
@@ -92,13 +95,19 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
   const float* xin = p.x + (long)(n / p.xni) * p.xsg + (long)(n % p.xni) * p.xsn;
   const int xsw = (int)p.xsw;
 
-  // transform items (halo row r, column quad t, channel quad c4), c4 fastest; round i owns q = tid + 512 i
+  // transform items (halo row r, column quad t, channel quad c4), c4 fastest; round i owns q = tid + 512 i.
+  // Round 0 = the 16 halo rows 1 .. 16 (the tile's own rows: 512 items, every thread one), round 1 = halo rows 0 and 17
+  // (64 items: wave 0 alone -- the wave every other wave of the block then waits for at the chunk's barrier).  When both
+  // of those rows lie outside the image -- every tile of a 16 x 16 image: the SeparableConv4d layers, 80 % of this
+  // kernel's work -- round 1 is all zeros: the two rows are zero-filled once and the round is skipped (round 4).
+  const bool r1_live = !MT_W43_SKIP_R1 || ty0 > 0 || ty0 + TH < HL;
   int it_row[RI], it_lx[RI], it_dst[RI];
   unsigned it_ok[RI];
 #pragma unroll
   for (int i = 0; i < RI; ++i) {
     const int q = tid + 512 * i;
-    const int c4 = q & 7, t = (q >> 3) & 3, r = q >> 5;
+    const int c4 = q & 7, t = (q >> 3) & 3, rq = q >> 5;
+    const int r = rq < TH ? rq + 1 : (rq == TH ? 0 : ROWS - 1);
     const int ly = ty0 - 1 + r;
     it_ok[i] = 0;
     it_lx[i] = tx0 - 1 + 4 * t;
@@ -157,11 +166,21 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
   {
     f32x4 r0[6], r1[6];
     load_item(r0, 0, 0);
-    load_item(r1, 1, 0);
+    if (r1_live) load_item(r1, 1, 0);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) { load_B(fb[0][ks], 0, 0, ks); load_B(fb[1][ks], 0, 1, ks); }
     store_item(r0, 0, 0);
-    store_item(r1, 1, 0);
+    if (r1_live) {
+      store_item(r1, 1, 0);
+    } else {
+      // halo rows 0 and ROWS - 1 of both images and both planes stay zero for the whole block
+      constexpr int ROW8 = ROW_E / 4;                        // 8-byte units per row
+      for (int e = tid; e < 2 * NS * 2 * ROW8; e += 512) {
+        const int u = e % ROW8, w_ = e / ROW8;               // w_: (buffer, plane, which row)
+        const int row = (w_ & 1) ? ROWS - 1 : 0, plane = (w_ >> 1) % NS, buf = w_ / (2 * NS);
+        *reinterpret_cast<bf16x4*>(sV + buf * BUF_E + plane * PLANE_E + row * ROW_E + 4 * u) = bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      }
+    }
   }
   f32x16 acc[TM][3];
 #pragma unroll
@@ -190,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
       const int slot = (w + PAR) & 1;                  // global tap counter 9 ch + w, modulo 2
       const int toff = ky * ROW_E + xl * NQ * ENT;
       // the next chunk's image: round 0 is loaded at tap 0 and written at tap 4, round 1 at taps 5 / 8
-      if ((w == 0 || w == 5) && more) load_item(rh, w == 0 ? 0 : 1, (ch + 1) * CK);
+      if ((w == 0 || (w == 5 && r1_live)) && more) load_item(rh, w == 0 ? 0 : 1, (ch + 1) * CK);
       bf16x8 fa[KSTEPS][TM][NS];
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks)
@@ -208,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
         if (w + 2 < TW_) load_B(fb[slot][ks], ch, w + 2, ks);
         else if (more) load_B(fb[slot][ks], ch + 1, w + 2 - TW_, ks);
       }
-      if ((w == 4 || w == 8) && more) store_item(rh, w == 4 ? 0 : 1, nb);
+      if ((w == 4 || (w == 8 && r1_live)) && more) store_item(rh, w == 4 ? 0 : 1, nb);
     }
     if (more) __syncthreads();      // the other image is complete, nobody reads this one any more
   };

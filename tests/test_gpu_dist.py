@@ -159,9 +159,10 @@ def _rank_graphed(rank, world, port, out, steps):
     from master_thesis_amd import dist as mdist
     from master_thesis_amd.graph import GraphedTrainStep
     model = mt.DFPN(mt.VGGFeatures(device=dev), **KW)
-    model.load_state_dict(S.add_buffers(S.seeded_state_dict(S.dfpn_shapes(), seed=rank)))       # ranks start apart ...
+    model.load_state_dict(S.add_buffers(S.seeded_state_dict(S.dfpn_shapes(), seed=0)))          # (the frozen VGG is the same everywhere)
     model = model.to(dev)
     opt = model.configure_optimizers()['optimizer']
+    opt.flat_p.add_(0.01 * rank)                                                                # the trainable ones start apart ...
     mdist.init_comm(dev)
     mdist.broadcast_parameters(opt)                                                             # ... and agree after this
     (x, m), y, info = S.synthetic_batch(world, 2, 64, 64, seed=31)                             # clip r belongs to rank r
