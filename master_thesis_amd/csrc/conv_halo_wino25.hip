@@ -32,6 +32,13 @@
 
 namespace {
 
+#ifndef MT_W25_SCALAR_XFORM
+#define MT_W25_SCALAR_XFORM 0         // (1: the input transform without packed-fp32 instructions; needs -fno-slp-vectorize)
+#endif
+#ifndef MT_W25_SPLIT
+#define MT_W25_SPLIT MT_SHADOW_DEFAULT   // split form of the transformed values (conv_common.h: split4f SHADOW)
+#endif
+
 template <int FMT>
 __global__ __launch_bounds__(512, 2) void igemm_wino25_kernel(ConvK p, int tiles_y, int tiles_x) {
   constexpr int NS = 2, CK = 32, TH = 8, TW = 16, BN = 128, TM = 2, NXI = 6, KY = 5;
@@ -109,14 +116,30 @@ __global__ __launch_bounds__(512, 2) void igemm_wino25_kernel(ConvK p, int tiles
   auto store_item = [&](const f32x4 (&d)[6], int i, int buf) {
     if (it_ok[i] & 64u) {
       // B^T d with shared terms: 12 multiply-adds for the six xi
+#if MT_W25_SCALAR_XFORM
+      // (round 4) element by element in plain fp32 instructions: no v_pk_*_f32 on the pipe the other wave's MFMAs need
+      f32x4 v[6];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d0 = d[0][j], d1 = d[1][j], d2 = d[2][j], d3 = d[3][j], d4 = d[4][j], d5 = d[5][j];
+        const float t0 = __builtin_fmaf(-4.f, d2, d4), t1 = __builtin_fmaf(-4.f, d1, d3), t2 = d4 - d2, t3 = d3 - d1;
+        v[0][j] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+        v[1][j] = t0 + t1;
+        v[2][j] = t0 - t1;
+        v[3][j] = __builtin_fmaf(2.f, t3, t2);
+        v[4][j] = __builtin_fmaf(-2.f, t3, t2);
+        v[5][j] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+      }
+#else
       const f32x4 t0 = d[4] - 4.f * d[2], t1 = d[3] - 4.f * d[1], t2 = d[4] - d[2], t3 = d[3] - d[1];
       const f32x4 v[6] = {4.f * d[0] - 5.f * d[2] + d[4], t0 + t1, t0 - t1, t2 + 2.f * t3, t2 - 2.f * t3,
                           4.f * d[1] - 5.f * d[3] + d[5]};
+#endif
       __bf16* dst = sV + buf * BUF_E + it_dst[i];
 #pragma unroll
       for (int xi = 0; xi < NXI; ++xi) {
         bf16x4 parts[NS];
-        split4f<NS, FMT>(v[xi], scA, parts);
+        split4f<NS, FMT, MT_W25_SPLIT>(v[xi], scA, parts);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
           *reinterpret_cast<bf16x4*>(dst + s * PLANE_E + xi * NTX * ENT) = parts[s];

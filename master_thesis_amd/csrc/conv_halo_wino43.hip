@@ -46,6 +46,12 @@ __device__ unsigned long long w43_trace[8192 * 8];
 #ifndef MT_W43_SKIP_R1
 #define MT_W43_SKIP_R1 1              // (0: A/B builds that always run the second transform round)
 #endif
+#ifndef MT_W43_SCALAR_XFORM
+#define MT_W43_SCALAR_XFORM 0         // (1: the input transform without packed-fp32 instructions; needs -fno-slp-vectorize)
+#endif
+#ifndef MT_W43_SPLIT
+#define MT_W43_SPLIT MT_SHADOW_DEFAULT   // split form of the transformed values (conv_common.h: split4f SHADOW)
+#endif
 #ifndef MT_W43_PREFETCH_AHEAD
 #define MT_W43_PREFETCH_AHEAD 32     // blocks of one XCD in flight: 32 CUs x one block
 #endif
@@ -135,14 +141,31 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
   auto store_item = [&](const f32x4 (&d)[6], int i, int buf) {
     if (it_ok[i] & 64u) {
       // B^T d with shared terms: 12 multiply-adds for the six xi
+#if MT_W43_SCALAR_XFORM
+      // (lab, round 4) element by element in plain fp32 instructions: on f32x4 values hipcc emits v_pk_fma_f32 /
+      // v_pk_add_f32 / v_pk_mul_f32, which run on the pipe the MFMAs of the SIMD's other wave need (scratch/lab/coissue.hip)
+      f32x4 v[6];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d0 = d[0][j], d1 = d[1][j], d2 = d[2][j], d3 = d[3][j], d4 = d[4][j], d5 = d[5][j];
+        const float t0 = __builtin_fmaf(-4.f, d2, d4), t1 = __builtin_fmaf(-4.f, d1, d3), t2 = d4 - d2, t3 = d3 - d1;
+        v[0][j] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+        v[1][j] = t0 + t1;
+        v[2][j] = t0 - t1;
+        v[3][j] = __builtin_fmaf(2.f, t3, t2);
+        v[4][j] = __builtin_fmaf(-2.f, t3, t2);
+        v[5][j] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+      }
+#else
       const f32x4 t0 = d[4] - 4.f * d[2], t1 = d[3] - 4.f * d[1], t2 = d[4] - d[2], t3 = d[3] - d[1];
       const f32x4 v[6] = {4.f * d[0] - 5.f * d[2] + d[4], t0 + t1, t0 - t1, t2 + 2.f * t3, t2 - 2.f * t3,
                           4.f * d[1] - 5.f * d[3] + d[5]};
+#endif
       __bf16* dst = sV + buf * BUF_E + it_dst[i];
 #pragma unroll
       for (int x6 = 0; x6 < NXI; ++x6) {
         bf16x4 parts[NS];
-        split4f<NS, FMT>(v[x6], scA, parts);
+        split4f<NS, FMT, MT_W43_SPLIT>(v[x6], scA, parts);
 #pragma unroll
         for (int s = 0; s < NS; ++s)
           *reinterpret_cast<bf16x4*>(dst + s * PLANE_E + x6 * NQ * ENT) = parts[s];
