@@ -105,7 +105,7 @@ __device__ __forceinline__ void igemm_epilogue(const ConvK& p, f32x16 (&acc)[TM]
 // kernel-uniform switches), element offsets are 32-bit, and the optional operands are read in
 // batches (all loads of a pass are in flight together) instead of one dependent load per element.
 // Returns max |v| over what was written.
-template <bool PRED, int NE, class PixFn>
+template <bool PRED, int NE, bool NTS = false, class PixFn>
 __device__ __forceinline__ float halo_epilogue_body(const ConvK& p, int n, int o, float (&v)[NE], PixFn pix,
                                                     unsigned long long okm) {
   float* yb = p.y + ((long)(n / p.yni) * p.ysg + (long)(n % p.yni) * p.ysn + o);
@@ -159,7 +159,8 @@ __device__ __forceinline__ float halo_epilogue_body(const ConvK& p, int n, int o
     int oy, ox;
     pix(e, oy, ox);
     if (ok(e)) {
-      yb[oy * ysh + ox * ysw] = v[e];
+      if constexpr (NTS) __builtin_nontemporal_store(v[e], yb + (oy * ysh + ox * ysw));      // (streamed: read by a later launch only)
+      else yb[oy * ysh + ox * ysw] = v[e];
       vmax = fmaxf(vmax, fabsf(v[e]));
     }
   }
@@ -168,7 +169,7 @@ __device__ __forceinline__ float halo_epilogue_body(const ConvK& p, int n, int o
 
 // (bv: the lane's bias value, 0 without one -- kernels that finish several tiles per lane read it before their main loop,
 // so that layers without residual / accumulate / gate operands issue no load after a store)
-template <int NE, class PixFn>
+template <int NE, bool NTS = false, class PixFn>
 __device__ __forceinline__ float halo_epilogue(const ConvK& p, int n, int o, float (&v)[NE], PixFn pix, float bv) {
   static_assert(NE <= 64, "one mask word");
   const bool lane_ok = o < p.Co;
@@ -193,8 +194,8 @@ __device__ __forceinline__ float halo_epilogue(const ConvK& p, int n, int o, flo
   }
   constexpr unsigned long long FULL = NE == 64 ? ~0ull : ((1ull << (NE & 63)) - 1);
   // interior tiles (almost all of them): no per-element predicate anywhere
-  if (__all(okm == FULL)) return halo_epilogue_body<false, NE>(p, n, o, v, pix, okm);
-  return halo_epilogue_body<true, NE>(p, n, o, v, pix, okm);
+  if (__all(okm == FULL)) return halo_epilogue_body<false, NE, NTS>(p, n, o, v, pix, okm);
+  return halo_epilogue_body<true, NE, NTS>(p, n, o, v, pix, okm);
 }
 template <int NE, class PixFn>
 __device__ __forceinline__ float halo_epilogue(const ConvK& p, int n, int o, float (&v)[NE], PixFn pix) {

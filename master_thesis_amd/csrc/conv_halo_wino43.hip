@@ -52,6 +52,15 @@ __device__ unsigned long long w43_trace[8192 * 8];
 #ifndef MT_W43_SPLIT
 #define MT_W43_SPLIT MT_SHADOW_DEFAULT   // split form of the transformed values (conv_common.h: split4f SHADOW)
 #endif
+#ifndef MT_W43_NT_LOAD
+#define MT_W43_NT_LOAD 0              // (lab: halo loads as non-temporal streams)
+#endif
+#ifndef MT_W43_NT_STORE
+#define MT_W43_NT_STORE 0             // (lab: output stores as non-temporal streams)
+#endif
+#ifndef MT_W43_NTILE_MAJOR
+#define MT_W43_NTILE_MAJOR 0          // (lab: block order n-tile major inside an XCD)
+#endif
 #ifndef MT_W43_PREFETCH_AHEAD
 #define MT_W43_PREFETCH_AHEAD 32     // blocks of one XCD in flight: 32 CUs x one block
 #endif
@@ -81,8 +90,16 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
   {
     const int q8 = npt >> 3, r8 = npt & 7;
     const int mine = q8 + (xcd < r8 ? 1 : 0), start = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+#if MT_W43_NTILE_MAJOR
+    // (lab) all pixel tiles of an XCD for n-tile 0, then for n-tile 1: the weight fragments in flight are ONE n-tile's
+    // (2.4 MB for a 256 -> 256 layer: fits the 4 MB L2) at the price of reading every halo from HBM / Infinity Cache twice
+    const int per = gridDim.x / 8 / ntn;            // block slots of this XCD per n-tile (the grid is padded to 8 * ceil(nt / 8) * ntn)
+    nty = lid / per;
+    const int tl = lid - nty * per;
+#else
     const int tl = lid / ntn;
     nty = lid - tl * ntn;
+#endif
     if (tl >= mine) {            // (a padding block: it still takes part in the launch's max reduction)
       finish_amax(p, 0.f, sV);
       return;
@@ -133,8 +150,13 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (((it_ok[i] >> b) & 1u) && cin)
+      if (((it_ok[i] >> b) & 1u) && cin) {
+#if MT_W43_NT_LOAD
+        v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xin + (it_row[i] + ((it_lx[i] + b) >> p.ups) * xsw + c0)));
+#else
         v = *reinterpret_cast<const f32x4*>(xin + (it_row[i] + ((it_lx[i] + b) >> p.ups) * xsw + c0));
+#endif
+      }
       d[b] = v;
     }
   };
@@ -335,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
       }
       // element (q, j): C/D row (r & 3) + 8 (r >> 2) + 4 lh -> output row 8 xh + 2 (r >> 2) + lh, column quad r & 3
       const int oyb = ty0 + 8 * xh + lh;
-      vmax = fmaxf(vmax, halo_epilogue<32>(p, n, o, vals, [&](int e, int& oy, int& ox) {
+      vmax = fmaxf(vmax, halo_epilogue<32, MT_W43_NT_STORE != 0>(p, n, o, vals, [&](int e, int& oy, int& ox) {
         const int r = 8 * hh + (e >> 2), j = e & 3;
         oy = oyb + 2 * (r >> 2);
         ox = tx0 + 4 * (r & 3) + j;
