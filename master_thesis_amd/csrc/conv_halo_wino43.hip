@@ -61,6 +61,9 @@ __device__ unsigned long long w43_trace[8192 * 8];
 #ifndef MT_W43_NTILE_MAJOR
 #define MT_W43_NTILE_MAJOR 0          // (lab: block order n-tile major inside an XCD)
 #endif
+#ifndef MT_W43_STAGGER
+#define MT_W43_STAGGER 0              // (lab: the two xi halves transform at different taps)
+#endif
 #ifndef MT_W43_PREFETCH_AHEAD
 #define MT_W43_PREFETCH_AHEAD 32     // blocks of one XCD in flight: 32 CUs x one block
 #endif
@@ -254,7 +257,12 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
       const int slot = (w + PAR) & 1;                  // global tap counter 9 ch + w, modulo 2
       const int toff = ky * ROW_E + xl * NQ * ENT;
       // the next chunk's image: round 0 is loaded at tap 0 and written at tap 4, round 1 at taps 5 / 8
+#if MT_W43_STAGGER
+      // (lab) the two waves of a SIMD are the two xi halves of one channel quarter: give them different taps for their VALU burst
+      if (((w == (xh ? 2 : 0)) || (w == (xh ? 6 : 4) && r1_live)) && more) load_item(rh, w == (xh ? 2 : 0) ? 0 : 1, (ch + 1) * CK);
+#else
       if ((w == 0 || (w == 5 && r1_live)) && more) load_item(rh, w == 0 ? 0 : 1, (ch + 1) * CK);
+#endif
       bf16x8 fa[KSTEPS][TM][NS];
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks)
@@ -272,7 +280,11 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
         if (w + 2 < TW_) load_B(fb[slot][ks], ch, w + 2, ks);
         else if (more) load_B(fb[slot][ks], ch + 1, w + 2 - TW_, ks);
       }
+#if MT_W43_STAGGER
+      if (((w == (xh ? 5 : 3)) || (w == 8 && r1_live)) && more) store_item(rh, w == 8 ? 1 : 0, nb);
+#else
       if ((w == 4 || (w == 8 && r1_live)) && more) store_item(rh, w == 4 ? 0 : 1, nb);
+#endif
     }
     if (more) __syncthreads();      // the other image is complete, nobody reads this one any more
   };

@@ -142,3 +142,91 @@ def test_bench_launcher_refuses_missing_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '1', '--warmup', '0'],
                        capture_output=True, text=True, env=env2, timeout=300)
     assert r.returncode == 2 and 'launcher started 1 rank' in r.stderr, (r.returncode, r.stderr[-300:])
+
+
+def _view(L, n, h, w, c):
+    return L.View(None, h * w * c, w * c, c, n, h, w, c, n, 0)
+
+
+def _conv_plan(L, n, h, w, cin_p, cout_p, k, stride=1, transposed=0, ups=0, prec=3, cin=None, cout=None, algo=0):
+    d = L.Conv()
+    ho, wo = ((h << ups, w << ups) if stride == 1 else ((h // 2, w // 2) if not transposed else (2 * h, 2 * w)))
+    d.x, d.y = _view(L, n, h, w, cin_p), _view(L, n, ho, wo, cout_p)
+    d.KH = d.KW = k
+    d.stride, d.pad, d.transposed, d.ups, d.precision, d.algo = stride, k // 2, transposed, ups, prec, algo
+    plan = L.ConvPlan()
+    L.call('mt_conv_plan_query', ctypes.byref(d), cin or cin_p, cout or cout_p, ctypes.byref(plan))
+    return plan
+
+
+def test_conv_plan_query_is_the_dispatch():
+    """mt_conv_plan_query (no GPU needed: nothing is launched) names the kernel family, the pack layout and the
+    arithmetic facts of every layer class of the two models -- the decision the host side used to mirror by hand."""
+    from master_thesis_amd import _lib as L
+    F16, BF3, BF6, F32 = L.PREC_F16X3, L.PREC_BF16X3, L.PREC_BF16X6, L.PREC_F32
+    cases = [
+        # (plan arguments, kernel label, wt_layout, executed / algorithmic products)
+        (dict(n=8192, h=16, w=16, cin_p=256, cout_p=256, k=3), 'igemm_wino43_kernel<f16>', L.WT_HALO, (1, 2)),      # SeparableConv4d
+        (dict(n=32, h=256, w=256, cin_p=128, cout_p=128, k=5), 'igemm_wino25_kernel<f16>', L.WT_HALO, (3, 5)),      # FlowEstimator 5x5
+        (dict(n=32, h=64, w=64, cin_p=160, cout_p=32, k=3), 'igemm_winox_kernel<f16,1>', L.WT_HALO, (2, 3)),        # dense-block growth conv
+        (dict(n=32, h=64, w=64, cin_p=192, cout_p=64, k=3), 'igemm_winox_kernel<f16,2>', L.WT_HALO, (2, 3)),        # conv5 / block-input gradient
+        (dict(n=32, h=256, w=256, cin_p=64, cout_p=64, k=3), 'igemm_halo_wino_kernel<f16,2>', L.WT_HALO, (2, 3)),   # RRDBNet 64 <-> 64
+        (dict(n=40, h=128, w=128, cin_p=128, cout_p=128, k=3, prec=BF3), 'igemm_wino16_kernel<bf16>', L.WT_HALO, (2, 3)),   # VGG
+        (dict(n=40, h=8, w=8, cin_p=128, cout_p=128, k=3, prec=BF3), 'igemm_halo_wino_kernel<bf16,1>', L.WT_HALO, (2, 3)),  # ... on 8-row images
+        (dict(n=32, h=256, w=256, cin_p=16, cout_p=128, k=5), 'igemm_halo_kernel<5,2,f16,2,2,2,2,16>', L.WT_HALO, (1, 1)),  # 10 -> 128 entry
+        (dict(n=32, h=256, w=256, cin_p=128, cout_p=128, k=5, ups=1), 'igemm_wino25_kernel<f16>', L.WT_HALO, (3, 5)),      # (ADVICE round 3)
+        (dict(n=32, h=128, w=128, cin_p=128, cout_p=128, k=3, prec=BF6), 'igemm_halo_kernel<3,3,bf16,2,2,2,2,16>', L.WT_HALO, (1, 1)),
+        (dict(n=32, h=256, w=256, cin_p=128, cout_p=128, k=5, stride=2), 'igemm_halo_planes_kernel<5,s2,c>', L.WT_PLANES, (1, 1)),
+        (dict(n=32, h=64, w=64, cin_p=128, cout_p=128, k=3, stride=2, transposed=1), 'igemm_halo_planes_kernel<3,s2,t>', L.WT_PLANES, (1, 1)),
+        (dict(n=32, h=64, w=64, cin_p=128, cout_p=128, k=3, prec=F32), 'igemm_kernel<2,2,2,2>', L.WT_ROWS, (1, 1)),
+        (dict(n=32, h=64, w=64, cin_p=128, cout_p=128, k=3, algo=1), 'igemm_split_kernel<2,2,2,2,2,f16>', L.WT_ROWS, (1, 1)),   # MT355_HALO=0
+    ]
+    for kw, kernel, layout, (num, den) in cases:
+        p = _conv_plan(L, **kw)
+        assert p.kernel.decode() == kernel, (kw, p.kernel.decode())
+        assert p.wt_layout == layout and (p.wino_num, p.wino_den) == (num, den), (kw, p.wt_layout, p.wino_num, p.wino_den)
+        assert p.products == {F32: 1, BF3: 3, BF6: 6, F16: 3}[kw.get('prec', F16)]
+    # the fp32 VALU kernels are offered by real channel counts
+    assert _conv_plan(L, 40, 256, 256, 8, 64, 3, cin=3, cout=64).tiny_in_ok == 1          # VGG conv1_1
+    assert _conv_plan(L, 8192, 16, 16, 8, 128, 3, cin=1, cout=128).tiny_in_ok == 1        # SeparableConv4d entry
+    assert _conv_plan(L, 32, 256, 256, 128, 8, 3, cin=128, cout=2).tiny_out_ok == 1       # FlowEstimator exit
+    assert _conv_plan(L, 32, 256, 256, 128, 8, 5, cin=128, cout=1).tiny_out_ok == 1
+    p = _conv_plan(L, 32, 64, 64, 64, 64, 3)
+    assert (p.tiny_in_ok, p.tiny_out_ok) == (0, 0)
+    with pytest.raises(L.MT355Error):
+        _conv_plan(L, 1, 8, 8, 64, 64, 3, prec=9)
+
+
+def test_wgrad_plan_query_is_the_dispatch():
+    from master_thesis_amd import _lib as L
+
+    def plan(n, h, w, a_p, b_p, k, stride=1, prec=L.PREC_F16X3, d_terms=1, skip=0, a=None, b=None):
+        d = L.Wgrad()
+        hg, wg = (h, w) if stride == 1 else (2 * h, 2 * w)
+        d.d, d.g = _view(L, n, h, w, a_p), _view(L, n, hg, wg, b_p)
+        d.KH = d.KW = k
+        d.stride, d.pad, d.precision, d.d_terms, d.skip_tiles = stride, k // 2, prec, d_terms, skip
+        out = L.WgradPlan()
+        L.call('mt_wgrad_plan_query', ctypes.byref(d), a or a_p, b or b_p, ctypes.byref(out))
+        return out
+    p = plan(8192, 16, 16, 256, 256, 3)                      # SeparableConv4d: producer / consumer, 8-row tiles with one term of dY
+    assert (p.halo, p.pc, p.thin, p.batchable, p.tile_rows, p.d_terms, p.products) == (1, 1, 0, 1, 8, 1, 2)
+    assert p.kernel.decode() == 'wgrad_pc_kernel<3,3,f16>' and p.blocks == 16 and p.ntiles == 8192 * 2 and p.bias_tap_ok == 1
+    p = plan(32, 256, 256, 128, 128, 3)                      # large images: 4-row tiles
+    assert (p.pc, p.tile_rows, p.ntiles, p.blocks) == (1, 4, 32 * 64 * 16, 4)
+    p = plan(32, 256, 256, 128, 128, 3, d_terms=2)
+    assert (p.d_terms, p.products) == (2, 3)
+    p = plan(32, 256, 256, 128, 128, 3, prec=L.PREC_BF16X3)  # the one-term wish is not honoured on bf16 terms (8 bits)
+    assert (p.pc, p.d_terms, p.products) == (1, 2, 3) and p.kernel.decode() == 'wgrad_pc_kernel<3,3,bf16>'
+    p = plan(32, 256, 256, 128, 128, 5)
+    assert p.kernel.decode() == 'wgrad_pc_kernel<5,2+2+1,f16>' and p.blocks == 4 and p.batchable == 0
+    p = plan(32, 256, 256, 128, 16, 5, b=10)                 # FlowEstimator's 10 -> 128 entry: four taps per B tile
+    assert (p.thin, p.blocks) == (1, 2) and p.kernel.decode() == 'wgrad_thin_kernel<5,f16>'
+    p = plan(32, 128, 128, 128, 128, 5, stride=2)            # stride-2 gathers on the single-role halo kernel, one term allowed
+    assert (p.halo, p.pc, p.d_terms, p.blocks) == (1, 0, 1, 8) and p.kernel.decode() == 'wgrad_halo_kernel<5,3+2,2,f16>'
+    p = plan(32, 64, 64, 128, 128, 3, prec=L.PREC_F32)       # the generic gather kernels: one block per (tile, tap)
+    assert (p.halo, p.blocks) == (0, 9) and p.kernel.decode() == 'wgrad_kernel<2,2,2,2>'
+    p = plan(40, 256, 256, 64, 8, 3, a=64, b=3)              # VGG conv1_1-type: the fp32 VALU kernel is offered
+    assert p.tiny_ok == 1
+    with pytest.raises(L.MT355Error):
+        plan(1, 8, 8, 64, 64, 3, d_terms=7)
