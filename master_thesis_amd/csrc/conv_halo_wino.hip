@@ -213,6 +213,9 @@ __device__ unsigned long long winox_trace[4096 * 16];
 #ifndef MT_WINOX_SHADOW       // split form of the transform (conv_common.h: split4f SHADOW): 1 = no instruction that shares the matrix pipe
 #define MT_WINOX_SHADOW 2
 #endif
+#ifndef MT_WINOX_ROTATE        // 1 (lab, no gain): the half transform round alternates between the wave pairs from block to block
+#define MT_WINOX_ROTATE 0
+#endif
 #ifndef MT_WINOX_ABL          // (lab ablations: 1 no halo loads, 2 no transform / split / image stores, 3 no MFMAs, 4 no weight loads, 5 no epilogue)
 #define MT_WINOX_ABL 0
 #endif
@@ -251,10 +254,15 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK
   const unsigned xbytes = (unsigned)(((long)(p.H - 1) * p.xsh + (long)(p.W - 1) * p.xsw + ((p.C + 3) & ~3)) * 4);
   const auto xsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, xbytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
+  // The last transform round is a half round (640 items on 256 threads): two of the four waves do three rounds, two do two.
+  // Which two alternates with the block, so that the blocks that share a CU (three of them, one wave each per SIMD) do
+  // not all put their extra round on the same two SIMDs (round 4: MT_WINOX_ROTATE).  (tid ^ 128 keeps the channel quad.)
+  const int rot = MT_WINOX_ROTATE ? (int)(((blockIdx.x >> 3) & 1u) << 7) : 0;
+  auto item_of = [&](int i) { return (i == RI - 1 ? (tid ^ rot) : tid) + 256 * i; };
   unsigned it_off[RI][4];
 #pragma unroll
   for (int i = 0; i < RI; ++i) {
-    const int q = tid + 256 * i;
+    const int q = item_of(i);
     const int c4 = q & 7, t = (q >> 3) & 7, r = q >> 6;
     const int ly = ty0 - 1 + r;
     const long row = (long)(ly >> p.ups) * p.xsh + 4 * c4;
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK
 #endif
 #pragma unroll
     for (int i = 0; i < RI; ++i) {
-      const int q = tid + 256 * i;
+      const int q = item_of(i);
       if (q < NIT) {
         const int c4 = q & 7, t = (q >> 3) & 7, r = q >> 6;
         const f32x4 d0 = rh[i][0], d1 = rh[i][1], d2 = rh[i][2], d3 = rh[i][3];
