@@ -8,7 +8,7 @@
 # usage: tools/collect_profiles.sh <tag> [dfpn|chn]     (chn: the CHN step alone, files named <tag>_..._chn_...)
 set -u
 export TMPDIR=/tmp
-tag=${1:-r01}
+tag=${1:-r04}
 mode=${2:-dfpn}
 if [ "$mode" = chn ]; then only=--no-dfpn; sfx=_chn; else only=--no-chn; sfx=; fi
 out=gpurun_out/profiles_$tag$sfx
