@@ -64,6 +64,9 @@ __device__ unsigned long long w43_trace[8192 * 8];
 #ifndef MT_W43_STAGGER
 #define MT_W43_STAGGER 0              // (lab: the two xi halves transform at different taps)
 #endif
+#ifndef MT_W43_ABL
+#define MT_W43_ABL 0                  // (lab ablations, bit mask: 1 no weight-fragment reloads, 2 no per-tap image reads, 4 no in-loop transform)
+#endif
 #ifndef MT_W43_PREFETCH_AHEAD
 #define MT_W43_PREFETCH_AHEAD 32     // blocks of one XCD in flight: 32 CUs x one block
 #endif
@@ -251,19 +254,28 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
     const bool more = ch + 1 < nchunk;
     const __bf16* vb = sV + PAR * BUF_E;
     const int nb = PAR ^ 1;
+#if MT_W43_ABL & 2
+    bf16x8 fa[KSTEPS][TM][NS];
+#endif
 #pragma unroll
     for (int w = 0; w < TW_; ++w) {
       const int ky = w / 3, xl = w % 3;
       const int slot = (w + PAR) & 1;                  // global tap counter 9 ch + w, modulo 2
       const int toff = ky * ROW_E + xl * NQ * ENT;
       // the next chunk's image: round 0 is loaded at tap 0 and written at tap 4, round 1 at taps 5 / 8
-#if MT_W43_STAGGER
+#if MT_W43_ABL & 4
+      (void)more;
+#elif MT_W43_STAGGER
       // (lab) the two waves of a SIMD are the two xi halves of one channel quarter: give them different taps for their VALU burst
       if (((w == (xh ? 2 : 0)) || (w == (xh ? 6 : 4) && r1_live)) && more) load_item(rh, w == (xh ? 2 : 0) ? 0 : 1, (ch + 1) * CK);
 #else
       if ((w == 0 || (w == 5 && r1_live)) && more) load_item(rh, w == 0 ? 0 : 1, (ch + 1) * CK);
 #endif
+#if MT_W43_ABL & 2             // (lab ablation bit 1: the image fragments are read for the first tap of a chunk only)
+      if (w == 0)
+#else
       bf16x8 fa[KSTEPS][TM][NS];
+#endif
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
@@ -277,10 +289,13 @@ __global__ __launch_bounds__(512, 2) void igemm_wino43_kernel(ConvK p, int tiles
 #pragma unroll
         for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(fa[ks][a], fb[slot][ks], acc[a][xl]);
         // this slot's next contents: the same k-step two taps on
+#if !(MT_W43_ABL & 1)          // (lab ablation bit 0: the weight fragments are never reloaded -- wrong results, timing only)
         if (w + 2 < TW_) load_B(fb[slot][ks], ch, w + 2, ks);
         else if (more) load_B(fb[slot][ks], ch + 1, w + 2 - TW_, ks);
+#endif
       }
-#if MT_W43_STAGGER
+#if MT_W43_ABL & 4
+#elif MT_W43_STAGGER
       if (((w == (xh ? 5 : 3)) || (w == 8 && r1_live)) && more) store_item(rh, w == 8 ? 1 : 0, nb);
 #else
       if ((w == 4 || (w == 8 && r1_live)) && more) store_item(rh, w == 4 ? 0 : 1, nb);
