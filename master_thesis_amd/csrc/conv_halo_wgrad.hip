@@ -244,7 +244,7 @@ struct WgOne {};
 // Rows of a pixel tile of wgrad_pc_kernel.  8-row tiles (possible with one term of D: no D_lo plane, and 72-element LDS
 // rows) pay on SMALL images only: on the 16 x 16 images of SeparableConv4d the G patch of a tile shrinks from 1.5x to
 // 1.25x its pixels (5.40 -> 5.03 ms for 256 -> 256 on 8192 images), on 128^2 / 256^2 images the doubled staging registers
-// spill and the 72-element rows cost bank conflicts (1.37 -> 1.43 ms).  engine.py mirrors this rule.
+// spill and the 72-element rows cost bank conflicts (1.37 -> 1.43 ms).  The rule itself is wgpc_tr() in dispatch.h (mt_wgrad_select; the host side asks mt_wgrad_plan_query).
 
 // DT = 1 (mt_wgrad.d_terms): D enters with its LEADING 16-bit term only -- two partial products (D_hi G_hi, D_hi G_lo)
 // instead of three, no D_lo plane staged or read.  D then carries 11 (fp16) significant bits: rounding errors that are
