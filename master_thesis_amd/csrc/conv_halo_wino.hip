@@ -216,6 +216,9 @@ __device__ unsigned long long winox_trace[4096 * 16];
 #ifndef MT_WINOX_ROTATE        // 1 (lab, no gain): the half transform round alternates between the wave pairs from block to block
 #define MT_WINOX_ROTATE 0
 #endif
+#ifndef MT_WINOX_PIPE          // 1 (lab, a tie): 32-wide tiles prefetch the next step's image fragments (two register sets)
+#define MT_WINOX_PIPE 0
+#endif
 #ifndef MT_WINOX_TOUCH         // 1 (lab, a tie): 32-wide tiles touch the halo of chunk c + 2 during chunk c (one dword per 128-byte line: L2 prefetch)
 #define MT_WINOX_TOUCH 0
 #endif
@@ -393,6 +396,54 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK
       }
     };
     load_B2(fb2, 0, 1);                         // tap 1 of chunk 0 (tap 0 is in fb[0] since the prologue)
+#if MT_WINOX_PIPE
+    // (round 4) the six (kernel row, k step) steps of a chunk as a software pipeline: the image fragments of step s + 1 are
+    // requested BEFORE the MFMAs of step s are issued (two register sets), so a step's six MFMAs no longer start with an
+    // exposed LDS round trip -- the block timeline shows a chunk's three taps taking 1.5 - 2.8 us for 0.4 us of matrix-pipe time
+    bf16x8 faA[TM][NS], faB[TM][NS];
+    auto read_fa = [&](bf16x8 (&f)[TM][NS], int step) {
+      const int toff = (step >> 1) * ROW_E + (step & 1) * 16;
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) f[a][s] = *reinterpret_cast<const bf16x8*>(&sV[s * PLANE_E + a_base[a] + toff]);
+    };
+    auto chunk = [&](auto parity, int ch) {
+      constexpr int P = decltype(parity)::value;
+      const bool more = ch + 1 < nchunk;
+      read_fa(faA, 0);
+      auto step = [&](auto sc, bf16x8 (&cur)[TM][NS], bf16x8 (&nxt)[TM][NS], bf16x8 (&bw)[KSTEPS][NS]) {
+        constexpr int S = decltype(sc)::value;
+        constexpr int ky = S >> 1, ks = S & 1;
+        if constexpr (S + 1 < 6) read_fa(nxt, S + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < TM; ++a) mfma_splitf<NS, FMT>(cur[a], bw[ks], acc[a][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (ks == 1) {
+          // this slot's next contents: the tap two on; then the halo (behind the fragments of taps 1 and 2 in the return order)
+          if (ky == 0) load_B2(bw, ch, 2);
+          else if (more) load_B2(bw, ch + 1, ky - 1);
+          if (ky == 0 && more) load_raw((ch + 1) * CK, S0{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+      using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+      if constexpr (P == 0) {
+        step(I0{}, faA, faB, fb[0]); step(I1{}, faB, faA, fb[0]); step(I2{}, faA, faB, fb2); step(I3{}, faB, faA, fb2);
+        step(I4{}, faA, faB, fb[0]); step(I5{}, faB, faA, fb[0]);
+      } else {
+        step(I0{}, faA, faB, fb2); step(I1{}, faB, faA, fb2); step(I2{}, faA, faB, fb[0]); step(I3{}, faB, faA, fb[0]);
+        step(I4{}, faA, faB, fb2); step(I5{}, faB, faA, fb2);
+      }
+      if (more) {
+        __syncthreads();            // every wave is done reading this chunk's image
+        store_v(S0{});
+        __syncthreads();
+      }
+    };
+#else
     auto chunk = [&](auto parity, int ch) {
       constexpr int P = decltype(parity)::value;
       const bool more = ch + 1 < nchunk;
@@ -442,6 +493,7 @@ __global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK
         if (ch == 0) WX_STAMP(7);
       }
     };
+#endif
     for (int ch = 0; ch < nchunk; ch += 2) {
       chunk(std::integral_constant<int, 0>{}, ch);
       if (ch + 1 < nchunk) chunk(std::integral_constant<int, 1>{}, ch + 1);
