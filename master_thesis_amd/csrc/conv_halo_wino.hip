@@ -216,6 +216,9 @@ __device__ unsigned long long winox_trace[4096 * 16];
 #ifndef MT_WINOX_ROTATE        // 1 (lab, no gain): the half transform round alternates between the wave pairs from block to block
 #define MT_WINOX_ROTATE 0
 #endif
+#ifndef MT_WINOX_OCC           // blocks per CU the 32-wide variant is compiled for (3: 168 registers)
+#define MT_WINOX_OCC 3
+#endif
 #ifndef MT_WINOX_PIPE          // 1 (lab, a tie): 32-wide tiles prefetch the next step's image fragments (two register sets)
 #define MT_WINOX_PIPE 0
 #endif
@@ -229,7 +232,7 @@ __device__ unsigned long long winox_trace[4096 * 16];
 #define MT_WINOX_ABL 0
 #endif
 template <int FMT, int TN>
-__global__ __launch_bounds__(256, TN == 1 ? 3 : 2) void igemm_winox_kernel(ConvK p, int tiles_y, int tiles_x) {
+__global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC : 2) void igemm_winox_kernel(ConvK p, int tiles_y, int tiles_x) {
   constexpr int NS = 2, CK = 32, TH = 8, TW = 16, BN = 32 * TN, TM = 2;
   constexpr int NTX = TW / 2, ROWS = TH + 2;
   constexpr int ENT = CK, ROW_E = 4 * NTX * ENT + 8, PLANE_E = ROWS * ROW_E;
