@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC : 2) void igemm_winox_k
   constexpr int NIT = ROWS * NTX * (CK / 4), RI = (NIT + 255) / 256;
   constexpr int KSTEPS = CK / 16;
   static_assert(4 * TN * 16 * 64 * 4 <= NS * PLANE_E * 2, "the epilogue exchange of one M tile must fit the image");
+#ifndef MT_WINOX_PLANAR
+#define MT_WINOX_PLANAR 0
+#endif
 #ifndef MT_WINOX_LDS_PAD      // (lab: extra LDS elements, to measure what one block per CU fewer costs)
 #define MT_WINOX_LDS_PAD 0
 #endif
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC : 2) void igemm_winox_k
   // offset beyond the descriptor's range and reads as zero: no predicate, no branch, no zero-fill and no 64-bit address
   // arithmetic per load (the loop was VALU-bound: 508 VALU instructions per chunk against 36 MFMAs, a third of them these).
   const unsigned xbytes = (unsigned)(((long)(p.H - 1) * p.xsh + (long)(p.W - 1) * p.xsw + ((p.C + 3) & ~3)) * 4);
-  const auto xsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, xbytes, 0x00020000);
+  const auto xsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xin), 0, MT_WINOX_PLANAR ? 0x7fffffffu : xbytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   // The last transform round is a half round (640 items on 256 threads): two of the four waves do three rounds, two do two.
   // Which two alternates with the block, so that the blocks that share a CU (three of them, one wave each per SIMD) do
@@ -288,6 +291,8 @@ __global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC : 2) void igemm_winox_k
   // TN == 1 with MT_WINOX_AHEAD: TWO register sets -- the halo of chunk c + 2 is requested during chunk c, a whole chunk
   // (~2.5 us) before it is transformed, instead of ~0.5 us before: the transform between the two barriers of a chunk no
   // longer waits for an HBM round trip (round 4).  Set = chunk parity; every other path uses set 0 only.
+  // (lab, MT_WINOX_PLANAR: the input as 32-channel planes [chunk][image][row][pixel][32] -- the view describes plane 0)
+  const int plane_b = MT_WINOX_PLANAR ? (int)((long)p.N * p.xsn * 4) : 0;
   constexpr int NSET = (TN == 1 && MT_WINOX_AHEAD) ? 2 : 1;
   f32x4 rh2[NSET][RI][4];
   auto load_raw = [&](int c0, auto set_c) {
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC : 2) void igemm_winox_k
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
 #if MT_WINOX_ABL != 1
-        rh[i][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsr, it_off[i][b] | cmask, c0 * 4, 0));
+        rh[i][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsr, it_off[i][b] | cmask, MT_WINOX_PLANAR ? (c0 >> 5) * plane_b : c0 * 4, 0));
 #else
         rh[i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
