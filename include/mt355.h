@@ -188,6 +188,19 @@ int mt_conv_plan_query(const mt_conv* d, int32_t cin_real, int32_t cout_real, mt
  * `slabs` ([splits][D.C][KH*KW][G.C] floats) and are reduced by
  * mt_wgrad_reduce, which also un-packs into the parameter's own layout.
  */
+/* One 64 x 64 channel tile of a weight-gradient launch made of FOUR 32-channel groups chosen freely: D channels
+ * 32*a[0].. and 32*a[1].., G channels 32*b[0].. and 32*b[1]...  `quads`: bit (2 i + j) set = the 32 x 32 product of
+ * a[i] with b[j] is wanted (the others are neither computed nor written); `bias` = 1: this tile also writes the bias
+ * sums of its two D groups (with_bias launches: exactly one tile per D group should).  For launches shared by
+ * several layers whose useful products do not fill 64-aligned tiles: the four growth convolutions of a dense block
+ * (model_chn.py:588-623, 32 outputs each from 64 / 96 / 128 / 160 inputs) need 14 such 32 x 32 products -- four
+ * tiles instead of the five 64-aligned ones. */
+typedef struct {
+  uint8_t a[2], b[2];
+  uint8_t quads, bias;
+  uint8_t reserved[2];
+} mt_wgrad_tile;
+#define MT_WGRAD_TILES_MAX 8
 typedef struct {
   mt_view d;
   mt_view g;
@@ -209,11 +222,15 @@ typedef struct {
                           (three partial products, fp32-grade); 1 = D's leading term only (two partial products: D
                           rounded to 11 / 8 significant bits, independent rounding errors per pixel, ~1e-4 relative on
                           a gradient summed over >= 10^5 pixels) -- a speed / accuracy choice of the caller */
+  int32_t n_tiles;     /* 0: the regular grid of 64-aligned channel tiles (skip_tiles applies).  1 .. MT_WGRAD_TILES_MAX:
+                          the launch computes exactly tiles[0 .. n_tiles) (skip_tiles must be 0) -- only where
+                          mt_wgrad_plan.tile_list_ok says so (the stride-1 3x3 producer / consumer kernel) */
+  mt_wgrad_tile tiles[MT_WGRAD_TILES_MAX];
 } mt_wgrad;
 
 int mt_wgrad_run(const mt_wgrad* d, void* stream);
 /* What mt_wgrad_run does with this geometry (read of `d`: the views' shapes and strides, KH, KW, stride, pad, ups,
- * precision, algo, skip_tiles, d_terms; `splits` and the pointers are not looked at): the caller sizes `splits` and
+ * precision, algo, skip_tiles, n_tiles, d_terms; `splits` and the pointers are not looked at): the caller sizes `splits` and
  * the slabs from it.  a_real / b_real: D's and G's channel counts before padding. */
 typedef struct {
   int32_t halo;          /* 1: the halo-tile family takes it (with_bias available), 0: the generic gather kernels */
@@ -227,6 +244,7 @@ typedef struct {
   int32_t d_terms;       /* 16-bit terms of D that will enter: 1 only where asked for AND the kernel has the form */
   int32_t tiny_ok;       /* 1: the geometry is one mt_wgrad_tiny_run serves (Conv2d layers only) */
   int32_t products;      /* MFMA partial products per multiply-add */
+  int32_t tile_list_ok;  /* 1: the kernel takes a tile list (mt_wgrad.n_tiles > 0) */
   char kernel[96];
 } mt_wgrad_plan;
 int mt_wgrad_plan_query(const mt_wgrad* d, int32_t a_real, int32_t b_real, mt_wgrad_plan* out);

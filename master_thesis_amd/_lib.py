@@ -31,11 +31,20 @@ class Conv(C.Structure):
                 ('x_amax', C.c_void_p), ('w_amax', C.c_void_p), ('y_amax', C.c_void_p)]
 
 
+class WgradTile(C.Structure):       # mt_wgrad_tile: a 64 x 64 channel tile made of four freely chosen 32-channel groups
+    _fields_ = [('a', C.c_uint8 * 2), ('b', C.c_uint8 * 2), ('quads', C.c_uint8), ('bias', C.c_uint8),
+                ('reserved', C.c_uint8 * 2)]
+
+
+WGRAD_TILES_MAX = 8
+
+
 class Wgrad(C.Structure):
     _fields_ = [('d', View), ('g', View), ('KH', i32), ('KW', i32),
                 ('stride', i32), ('pad', i32), ('ups', i32), ('splits', i32),
                 ('slabs', C.c_void_p), ('precision', i32), ('algo', i32), ('with_bias', i32),
-                ('d_amax', C.c_void_p), ('g_amax', C.c_void_p), ('skip_tiles', C.c_uint32), ('d_terms', i32)]
+                ('d_amax', C.c_void_p), ('g_amax', C.c_void_p), ('skip_tiles', C.c_uint32), ('d_terms', i32),
+                ('n_tiles', i32), ('tiles', WgradTile * WGRAD_TILES_MAX)]
 
 
 class ConvPlan(C.Structure):       # mt_conv_plan
@@ -46,7 +55,7 @@ class ConvPlan(C.Structure):       # mt_conv_plan
 class WgradPlan(C.Structure):      # mt_wgrad_plan
     _fields_ = [('halo', i32), ('pc', i32), ('thin', i32), ('batchable', i32), ('tile_rows', i32), ('ntiles', i32),
                 ('blocks', i32), ('bias_tap_ok', i32), ('d_terms', i32), ('tiny_ok', i32), ('products', i32),
-                ('kernel', C.c_char * 96)]
+                ('tile_list_ok', i32), ('kernel', C.c_char * 96)]
 
 
 PATH_IGEMM, PATH_HALO, PATH_PLANES = 0, 1, 2

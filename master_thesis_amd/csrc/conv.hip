@@ -16,6 +16,7 @@
 // which keeps the b128 reads conflict-free.
 #include "common.h"
 #include "conv_common.h"
+#include "dispatch.h"
 
 namespace {
 
@@ -870,6 +871,7 @@ extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
   MT_REQUIRE((HL + 2 * d->pad - d->KH) / d->stride + 1 == d->d.H && (WL + 2 * d->pad - d->KW) / d->stride + 1 == d->d.W,
              "mt_wgrad: dense tensor %dx%d is not conv(gathered %dx%d)", d->d.H, d->d.W, HL, WL);
   MT_REQUIRE((int64_t)d->d.N * d->d.H * d->d.W < (1ll << 31), "mt_wgrad: too many pixels");
+  { const int rc = mt_wgrad_tiles_check(d, mt_wgrad_select(d)); if (rc) return rc; }
   if (d->algo == MT_ALGO_AUTO && mt_wgrad_halo_try_launch(d, stream)) return mt_check_launch("mt_wgrad_run(halo)");
   MT_REQUIRE(!d->with_bias, "mt_wgrad: with_bias is only available on the halo-tile path (stride 1, 3x3/5x5, split precision)");
   WgK k;
@@ -883,7 +885,7 @@ extern "C" int mt_wgrad_run(const mt_wgrad* d, void* stream) {
   MT_REQUIRE((int64_t)k.per_split * d->splits >= k.M, "mt_wgrad: split arithmetic");
   k.slabs = d->slabs;
   k.damax = d->d_amax; k.gamax = d->g_amax;
-  k.skip = 0;
+  k.skip = 0; k.ntl = 0;
   int cfg;
   wgrad_cfg(d, &k.atiles, &k.btiles, &cfg);
   dim3 grid(k.atiles * k.btiles * d->KH * d->KW, d->splits);

@@ -488,7 +488,20 @@ struct WgK {
   float* slabs;
   const float* damax; const float* gamax;   // F16X3: device scalars max|D|, max|G|
   unsigned skip;                            // halo path: bit (at*btiles+bt) = tile not wanted
+  // wgrad_pc_kernel (3 x 3): ntl > 0 = the launch computes the tiles of this list instead of the 64-aligned grid
+  // (mt_wgrad.tiles, one 64-bit word each: a[0] | a[1] << 8 | b[0] << 16 | b[1] << 24 | quads << 32 | bias << 40)
+  int ntl;
+  unsigned long long tl[MT_WGRAD_TILES_MAX];
 };
+inline void wgk_tiles(const mt_wgrad* d, WgK* k) {
+  k->ntl = d->n_tiles;
+  for (int i = 0; i < MT_WGRAD_TILES_MAX; ++i) {
+    const mt_wgrad_tile& t = d->tiles[i];
+    k->tl[i] = i < d->n_tiles ? ((unsigned long long)t.a[0] | (unsigned long long)t.a[1] << 8 | (unsigned long long)t.b[0] << 16 |
+                                 (unsigned long long)t.b[1] << 24 | (unsigned long long)(t.quads & 15) << 32 |
+                                 (unsigned long long)(t.bias ? 1 : 0) << 40) : 0ull;
+  }
+}
 
 inline int fill_convk(const mt_conv* d, ConvK* k) {
   MT_REQUIRE(d, "mt_conv: null descriptor");

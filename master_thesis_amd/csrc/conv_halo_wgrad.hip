@@ -11,6 +11,7 @@
 #ifndef MT_WGPC_SHADOW
 #define MT_WGPC_SHADOW 1
 #endif
+#include <cstring>
 #include "conv_common.h"
 #include "dispatch.h"
 
@@ -267,12 +268,28 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave >= 4;
+  // The block's 64 x 64 channel tile = four 32-channel groups: D channels aA.., aB.. (tile columns 0-31 / 32-63 of the
+  // staged D image), G channels bA.., bB...  Regular grid: 64-aligned tiles (aB = aA + 32).  Tile list (mt_wgrad.tiles,
+  // 3 x 3 only): the groups are free, `quads` says which of the four 32 x 32 products (one per MFMA wave) are wanted.
   int bid = blockIdx.x;
-  const int bt = bid % p.btiles; bid /= p.btiles;
-  const int at = bid % p.atiles; bid /= p.atiles;
-  const int kh0 = kh_base + bid * KHB;
-  if (at * p.btiles + bt < 32 && ((p.skip >> (at * p.btiles + bt)) & 1u)) return;   // tile nobody reads
-  const int a0 = at * CH, b0 = bt * CH;
+  int aA, aB, bA, bB, kh0;
+  unsigned quads = 15u;
+  bool bias_tile;
+  if (KS == 3 && p.ntl > 0) {
+    const int ti = bid % p.ntl; bid /= p.ntl;
+    const unsigned long long e = p.tl[ti];
+    aA = (int)(e & 255u) * 32; aB = (int)((e >> 8) & 255u) * 32; bA = (int)((e >> 16) & 255u) * 32; bB = (int)((e >> 24) & 255u) * 32;
+    quads = (unsigned)(e >> 32) & 15u;
+    bias_tile = ((e >> 40) & 1u) != 0;
+    kh0 = kh_base + bid * KHB;
+  } else {
+    const int bt = bid % p.btiles; bid /= p.btiles;
+    const int at = bid % p.atiles; bid /= p.atiles;
+    kh0 = kh_base + bid * KHB;
+    if (at * p.btiles + bt < 32 && ((p.skip >> (at * p.btiles + bt)) & 1u)) return;   // tile nobody reads
+    aA = at * CH; aB = aA + 32; bA = bt * CH; bB = bA + 32;
+    bias_tile = bt == 0;
+  }
   const int split = blockIdx.y;
   const float *pd, *pg, *pdamax, *pgamax;
   float* pslabs;
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
   // the fp32 values they load anyway -- every D pixel passes through exactly one of their registers -- in plain fp32:
   // no MFMAs for it on the consumer side, and independent of how many 16-bit terms of D the products use (with
   // d_terms = 1 a bias gradient that is a small difference of large sums would otherwise inherit D's 11-bit rounding).
-  const bool do_bias = with_bias && bt == 0 && kh0 == 0;
+  const bool do_bias = with_bias && bias_tile && kh0 == 0;
   if (producer) {
     // ---- waves 4-7: global -> registers -> split -> LDS, one tile ahead of the consumers --------
     const int ptid = tid - 256;
@@ -305,16 +322,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
     // multiplies made the staging waves VALU-bound and kept the MFMA waves waiting at the barrier.)
     // D: float4 idx = ptid + 256 i  ->  pixel row i, column ptid >> 4, channels 4 (ptid & 15)
     const int rxD = ptid >> 4, c4 = (ptid & 15) * 4;
-    const bool chD = a0 + c4 < p.Cd, chG = b0 + c4 < p.Cg, ch_full = a0 + CH <= p.Cd && b0 + CH <= p.Cg;
+    const int acD = (c4 < 32 ? aA : aB - 32) + c4, bcG = (c4 < 32 ? bA : bB - 32) + c4;      // this thread's first D / G channel
+    const bool chD = acD < p.Cd, chG = bcG < p.Cg, ch_full = aA + 32 <= p.Cd && aB + 32 <= p.Cd && bA + 32 <= p.Cg && bB + 32 <= p.Cg;
     const unsigned dsh = (unsigned)p.dsh, dsw = (unsigned)p.dsw, gsh = (unsigned)p.gsh, gsw = (unsigned)p.gsw;
-    const unsigned offD0 = rxD * dsw + a0 + c4;
+    const unsigned offD0 = rxD * dsw + acD;
     unsigned offG[RG];          // patch pixel -> element offset from the patch origin (ups == 0)
     int gyx[RG];                // patch pixel coordinates, gy << 8 | gx
 #pragma unroll
     for (int i = 0; i < RG; ++i) {
       const int gpx = (ptid >> 4) + 16 * i, gy = gpx / GW, gx = gpx - gy * GW;
       gyx[i] = gy << 8 | gx;
-      offG[i] = gy * gsh + gx * gsw + b0 + c4;
+      offG[i] = gy * gsh + gx * gsw + bcG;
     }
     auto load_tile = [&](int t, auto set_c) {
       constexpr int S = decltype(set_c)::value;
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
           const int ly = gy0 + (gyx[i] >> 8), lx = gx0 + (gyx[i] & 255);
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
           if (ptid + 256 * i < NG4 && (unsigned)ly < (unsigned)HL && (unsigned)lx < (unsigned)WL && chG) {
-            const unsigned off = __umul24(ly >> p.ups, gsh) + __umul24(lx >> p.ups, gsw) + b0 + c4;
+            const unsigned off = __umul24(ly >> p.ups, gsh) + __umul24(lx >> p.ups, gsw) + bcG;
             v = *reinterpret_cast<const f32x4*>(gimg + off);
           }
           rg[S][i] = v;
@@ -410,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
       float* slab = pslabs + (long)split * p.Cd * TSb * p.Cg;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int ai = a0 + lane * 4 + j;
+        const int ai = (lane < 8 ? aA : aB - 32) + lane * 4 + j;
         const float v = (bl[lane * 4 + j] + bl[64 + lane * 4 + j]) + (bl[128 + lane * 4 + j] + bl[192 + lane * 4 + j]);
         if (ai < p.Cd) slab[((long)ai * TSb + p.KH * p.KW) * p.Cg] = v;
       }
@@ -420,6 +438,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
 
   // ---- waves 0-3: MFMAs only ------------------------------------------------------------------
   const int wm = wave >> 1, wn = wave & 1;
+  const bool active = ((quads >> (wm * 2 + wn)) & 1u) != 0;      // (wave-uniform: a listed tile may not want this wave's product)
   f32x16 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -440,6 +459,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
     // (Requesting row r + 1 before the MFMAs of row r -- a fourth D slot and a second G set -- was
     // measured and gained nothing: 1.87 vs 1.89 ms on the 256 x 256 x 128 x 128 layer.)
     bf16x8 fa[KHB][NS];
+    if (active) {
 #pragma unroll
     for (int r = 0; r < GH; ++r) {
       bf16x8 fb[KS][NS];
@@ -471,9 +491,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
         }
       }
     }
+    }
     __syncthreads();
   }
   __syncthreads();                           // (the staging waves' bias sums pass through LDS behind this barrier)
+  if (!active) return;
 
   const int T = p.KH * p.KW, li = lane & 31;
   const int TS = T + (with_bias ? 1 : 0);
@@ -483,8 +505,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
     const int tap = (kh0 + t / KS) * KS + (t % KS);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int ai = a0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int bi = b0 + wn * 32 + li;
+      const int ai = (wm ? aB : aA) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int bi = (wn ? bB : bA) + li;
       if (ai < p.Cd && bi < p.Cg) slab[((long)ai * TS + tap) * p.Cg + bi] = acc[t][r] * inv;
     }
   }
@@ -679,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_thin_kernel(WgK p, int tiles_y, 
 int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   const int prec = d->precision;
   const MtWgradSel sel = mt_wgrad_select(d);          // (dispatch.cpp: the one place that chooses)
-  if (!sel.halo) return 0;
+  if (!sel.halo) return 0;                            // (a tile list was checked by mt_wgrad_run: mt_wgrad_tiles_check)
   if (prec == MT_PREC_F16X3 && (!d->d_amax || !d->g_amax)) return 0;
   WgK k;
   k.d = d->d.p; k.dsn = d->d.sn; k.dsh = d->d.sh; k.dsw = d->d.sw; k.Hd = d->d.H; k.Wd = d->d.W; k.Cd = d->d.C;
@@ -691,7 +713,9 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   k.slabs = d->slabs;
   k.damax = d->d_amax; k.gamax = d->g_amax;
   k.skip = d->skip_tiles;
+  wgk_tiles(d, &k);
   const bool pc = sel.pc, tall = sel.tall, thin = sel.thin;
+  const unsigned ctiles = k.ntl > 0 ? k.ntl : k.atiles * k.btiles;      // channel tiles of a producer / consumer launch
   const int trows = sel.trows, dterms = sel.d_terms;
   const int tiles_y = (k.Hd + trows - 1) / trows, tiles_x = (k.Wd + 15) / 16;
   const int ntiles = d->d.N * tiles_y * tiles_x;
@@ -703,8 +727,8 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   do { if (dterms == 1) hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2, 4, 1>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE); \
        else hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE); } while (0)
 #define MT_WGPC(KS, KHB, FMT, KH_BASE) \
-  do { if (dterms == 1) hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT, false, 1>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); \
-       else hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); } while (0)
+  do { if (dterms == 1) hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT, false, 1>), dim3(ctiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); \
+       else hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(ctiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); } while (0)
   if (thin) {
     const dim3 grid(k.atiles, d->splits);
     if (d->KH == 3) {
@@ -719,7 +743,7 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   if (pc) {
     const bool f16 = prec == MT_PREC_F16X3;
     if (d->KH == 3 && f16 && trows == 8)
-      hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, false, 1, 8>), dim3(k.atiles * k.btiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, WgOne{});
+      hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, false, 1, 8>), dim3(ctiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, WgOne{});
     else if (d->KH == 3) { if (f16) MT_WGPC(3, 3, 1, 0); else MT_WGPC(3, 3, 0, 0); }
     // 5 x 5: kernel rows {0,1} | {2,3} | {4} (15 accumulator tiles would not leave the MFMA waves
     // their operand registers at two waves per SIMD; the staging is off the critical path here)
@@ -784,7 +808,8 @@ extern "C" int mt_wgrad_run_batch(const mt_wgrad* descs, int32_t n, void* stream
                       e->g.sh == d->g.sh && e->g.sw == d->g.sw && e->g.n_in == d->g.n_in && e->g.sg == d->g.sg &&
                       e->KH == d->KH && e->KW == d->KW && e->stride == d->stride && e->pad == d->pad && e->ups == d->ups &&
                       e->splits == d->splits && e->precision == d->precision && e->algo == d->algo &&
-                      e->with_bias == d->with_bias && e->skip_tiles == d->skip_tiles && e->d_terms == d->d_terms;
+                      e->with_bias == d->with_bias && e->skip_tiles == d->skip_tiles && e->d_terms == d->d_terms &&
+                      e->n_tiles == d->n_tiles && memcmp(e->tiles, d->tiles, sizeof(d->tiles)) == 0;
     MT_REQUIRE(same, "mt_wgrad_run_batch: problem %d differs from problem 0 in geometry", i);
     MT_REQUIRE(e->d.p && e->g.p && e->slabs && (reinterpret_cast<uintptr_t>(e->d.p) & 15) == 0 && (reinterpret_cast<uintptr_t>(e->g.p) & 15) == 0,
                "mt_wgrad_run_batch: problem %d: null / unaligned pointers", i);
@@ -800,13 +825,15 @@ extern "C" int mt_wgrad_run_batch(const mt_wgrad* descs, int32_t n, void* stream
   k.M = d->d.N * d->d.H * d->d.W; k.per_split = 0;
   k.atiles = (k.Cd + 63) / 64; k.btiles = (k.Cg + 63) / 64;
   k.slabs = d->slabs; k.damax = d->d_amax; k.gamax = d->g_amax; k.skip = d->skip_tiles;
+  wgk_tiles(d, &k);
   const MtWgradSel sel = mt_wgrad_select(d);
+  { const int rc = mt_wgrad_tiles_check(d, sel); if (rc) return rc; }
   MT_REQUIRE(sel.halo && sel.pc, "mt_wgrad_run_batch: the producer / consumer kernel does not take this layer (mt_wgrad_plan_query)");
   const int trb = prec == MT_PREC_F16X3 ? wgpc_tr(sel.d_terms, 3, k.Hd) : 4, dterms = sel.d_terms;
   const int tiles_y = (k.Hd + trb - 1) / trb, tiles_x = (k.Wd + 15) / 16;
   const int ntiles = d->d.N * tiles_y * tiles_x;
   const int tps = (ntiles + d->splits - 1) / d->splits;
-  const dim3 grid(k.atiles * k.btiles, d->splits, n);
+  const dim3 grid(k.ntl > 0 ? k.ntl : k.atiles * k.btiles, d->splits, n);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (prec == MT_PREC_F16X3 && dterms == 1 && trb == 8)
     hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, true, 1, 8>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);

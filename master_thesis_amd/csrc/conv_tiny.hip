@@ -413,7 +413,7 @@ extern "C" int mt_wgrad_tiny_run(const mt_wgrad* d, int32_t tiny, void* stream) 
   k.dni = d->d.n_in; k.dsg = d->d.sg; k.gni = d->g.n_in; k.gsg = d->g.sg;
   k.KH = 3; k.KW = 3; k.stride = 1; k.pad = 1; k.ups = 0;
   k.M = d->d.N * d->d.H * d->d.W; k.per_split = 0; k.atiles = k.btiles = 1;
-  k.slabs = d->slabs; k.damax = k.gamax = nullptr; k.skip = 0;
+  k.slabs = d->slabs; k.damax = k.gamax = nullptr; k.skip = 0; k.ntl = 0;
   const int rows = wc == 128 ? 8 : 16;
   const int tiles_y = (k.Hd + rows - 1) / rows, tiles_x = (k.Wd + 15) / 16;
   const long nt = (long)d->d.N * tiles_y * tiles_x;

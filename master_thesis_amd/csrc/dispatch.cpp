@@ -110,14 +110,30 @@ MtWgradSel mt_wgrad_select(const mt_wgrad* d) {
   // single-role 3 x 3 stride 1 (two-term splits): 8-row pixel tiles (+6 %; the 5 x 5 gradient loses 3 % with them)
   s.tall = !s.pc && d->stride == 1 && d->KH == 3 && prec != MT_PREC_BF16X6 && sw.wgrad3_tall;
   // 16 gathered channels (and no up-sampled gather): four taps share a B tile
-  s.thin = s.pc && sw.wgrad_thin && d->g.C == 16 && d->ups == 0 && !d->skip_tiles;
+  s.thin = s.pc && sw.wgrad_thin && d->g.C == 16 && d->ups == 0 && !d->skip_tiles && !d->n_tiles;
   // one term of D: fp16 terms only (the leading bf16 term has 8 bits), on the kernels that have the form
   // (producer / consumer; the stride-2 gathers of the single-role kernel)
   s.d_terms = (prec == MT_PREC_F16X3 && d->d_terms == 1 && ((s.pc && !s.thin) || d->stride == 2)) ? 1 : 2;
   s.trows = s.tall ? 8 : ((s.pc && !s.thin && prec == MT_PREC_F16X3) ? wgpc_tr(s.d_terms, d->KH, d->d.H) : 4);
   s.rows5 = !s.pc && d->stride == 1 && d->KH == 5 && (prec == MT_PREC_BF16X6 || sw.wgrad5_rows);
   if (d->KH == 5) s.launches = s.thin ? 1 : (s.pc ? 3 : (s.rows5 ? 1 : 2));
+  // a tile list (mt_wgrad.tiles): the 3 x 3 producer / consumer kernel only
+  s.tile_list = s.pc && !s.thin && d->KH == 3;
   return s;
+}
+
+int mt_wgrad_tiles_check(const mt_wgrad* d, const MtWgradSel& sel) {
+  MT_REQUIRE(d->n_tiles >= 0 && d->n_tiles <= MT_WGRAD_TILES_MAX, "mt_wgrad: n_tiles must be 0 .. %d (got %d)", MT_WGRAD_TILES_MAX, d->n_tiles);
+  if (d->n_tiles == 0) return MT_OK;
+  MT_REQUIRE(sel.halo && sel.tile_list, "mt_wgrad: this layer's kernel takes no tile list (mt_wgrad_plan.tile_list_ok)");
+  MT_REQUIRE(d->skip_tiles == 0, "mt_wgrad: a tile list and skip_tiles exclude one another");
+  for (int i = 0; i < d->n_tiles; ++i) {
+    const mt_wgrad_tile& t = d->tiles[i];
+    MT_REQUIRE(32 * t.a[0] < d->d.C && 32 * t.a[1] < d->d.C && 32 * t.b[0] < d->g.C && 32 * t.b[1] < d->g.C,
+               "mt_wgrad: tile %d names a 32-channel group outside D (%d channels) or G (%d)", i, d->d.C, d->g.C);
+    MT_REQUIRE(t.quads >= 1 && t.quads <= 15, "mt_wgrad: tile %d wants no product (quads = %d)", i, t.quads);
+  }
+  return MT_OK;
 }
 
 // ---- plan queries -------------------------------------------------------------------------------------------------------
@@ -185,6 +201,7 @@ extern "C" int mt_wgrad_plan_query(const mt_wgrad* d, int32_t a_real, int32_t b_
   memset(out, 0, sizeof(*out));
   const int prec = d->precision, K = d->KH, ap = d->d.C, bp = d->g.C, T = K * K;
   const MtWgradSel s = mt_wgrad_select(d);
+  { const int rc = mt_wgrad_tiles_check(d, s); if (rc) return rc; }
   out->halo = s.halo;
   out->pc = s.pc; out->thin = s.thin; out->d_terms = s.d_terms; out->tile_rows = s.trows;
   out->products = products_of(prec);
@@ -193,8 +210,9 @@ extern "C" int mt_wgrad_plan_query(const mt_wgrad* d, int32_t a_real, int32_t b_
                  lo <= 4 && (hi == 64 || hi == 128) && (ap > bp ? ap : bp) == hi && d->d.H == d->g.H && d->d.W == d->g.W;
   if (s.halo) {
     out->ntiles = d->d.N * ((d->d.H + s.trows - 1) / s.trows) * ((d->d.W + 15) / 16);
-    const int tiles64 = ((ap + 63) / 64) * ((bp + 63) / 64);
+    const int tiles64 = d->n_tiles > 0 ? d->n_tiles : ((ap + 63) / 64) * ((bp + 63) / 64);
     out->blocks = s.thin ? (ap + 63) / 64 : tiles64 * (s.pc ? 1 : (K == 3 ? 1 : (s.rows5 ? 5 : 2)));
+    out->tile_list_ok = s.tile_list;
     out->bias_tap_ok = 1;
     if (s.pc && s.d_terms == 1 && s.trows == 4) out->products = 2;
     if (s.pc && s.d_terms == 1 && s.trows == 8) out->products = 2;

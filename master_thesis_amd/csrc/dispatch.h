@@ -67,6 +67,8 @@ struct MtWgradSel {
   int trows;      // pixel-tile rows (4 / 8)
   int d_terms;    // 16-bit terms of D that enter (1 / 2): the caller's wish where the kernel has the form, else 2
   int launches;   // kernel launches per call (5 x 5: 3 for pc, 2 for the single-role kernel)
+  int tile_list;  // 1: the kernel takes mt_wgrad.tiles (3 x 3 producer / consumer)
 };
 inline int wgpc_tr(int d_terms, int KS, int Hd) { return (d_terms == 1 && KS == 3 && Hd <= 16 && (Hd & 7) == 0) ? 8 : 4; }
 MtWgradSel mt_wgrad_select(const mt_wgrad* d);
+int mt_wgrad_tiles_check(const mt_wgrad* d, const MtWgradSel& sel);   // MT_OK, or the error of a malformed / unsupported tile list

@@ -91,6 +91,10 @@ WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '512'))     # bloc
 # Forward and backward-DATA products always keep both terms of both operands.  The field is a WISH: the library applies it
 # where the kernel has the form (fp16 terms, producer / consumer and stride-2 kernels: mt_wgrad_plan.d_terms).
 WGRAD_D_TERMS = int(os.environ.get('MT355_WGRAD_D_TERMS', '1'))
+# Launches shared by several layers (the four growth convolutions of a dense block): cover their useful 32 x 32 channel
+# products with tiles of freely chosen 32-channel groups (mt_wgrad.tiles, tile_cover below) instead of 64-aligned tiles
+# with a skip mask (0: A/B).
+WGRAD_TILE_LIST = os.environ.get('MT355_WGRAD_TILE_LIST', '1') != '0'
 
 # ---- which kernel runs: asked from the library, never decided here ------------------------------------------------
 # Rounds 1-3 mirrored the C dispatch rules in this file.  Now the library's own
@@ -122,10 +126,43 @@ def _conv_plan(d, cin_real, cout_real):
     return hit
 
 
+def _tiles_key(d):
+    """The tile list of an mt_wgrad as a hashable value."""
+    return (d.n_tiles, bytes(d.tiles)) if d.n_tiles else 0
+
+
+def tile_cover(need, na, nb):
+    """Cover the wanted 32 x 32 channel products ``need`` = {(D group, G group)} with 64 x 64 tiles made of two D groups
+    x two G groups chosen freely (mt_wgrad_tile): greedy, most still-uncovered products first, compact tiles on ties.
+    Returns [(a0, a1, b0, b1, quads)], quads bit (2 i + j) = the product of D group i with G group j of the tile is
+    wanted (a product one tile has delivered is masked in the later ones).  The four growth convolutions of a dense
+    block (32 outputs from 64 / 96 / 128 / 160 inputs: 14 products) come out as 4 tiles against five 64-aligned ones."""
+    remaining, tiles = set(need), []
+    while remaining:
+        best = None
+        for a0 in range(na):
+            for a1 in range(a0, na):
+                for b0 in range(nb):
+                    for b1 in range(b0, nb):
+                        cnt = len({(a0, b0), (a0, b1), (a1, b0), (a1, b1)} & remaining)
+                        rank = (cnt, -(a1 - a0) - (b1 - b0))
+                        if best is None or rank > best[0]:
+                            best = (rank, (a0, a1, b0, b1))
+        a0, a1, b0, b1 = best[1]
+        quads = 0
+        for i, ga in enumerate((a0, a1)):
+            for j, gb in enumerate((b0, b1)):
+                if (ga, gb) in remaining:
+                    quads |= 1 << (2 * i + j)
+                    remaining.discard((ga, gb))
+        tiles.append((a0, a1, b0, b1, quads))
+    return tiles
+
+
 def _wgrad_plan(d, a_real, b_real):
     """(precision name, mt_wgrad_plan, label) of the weight gradient ``d`` describes (geometry, skip_tiles, d_terms set)."""
     key = (d.d.N, d.d.H, d.d.W, d.d.C, d.d.sh, d.d.sw, d.g.H, d.g.W, d.g.C, d.g.sh, d.g.sw, d.KH, d.stride, d.pad, d.ups,
-           d.algo, d.skip_tiles, d.d_terms, PRECISION, PRECISION_GENERIC, a_real, b_real)
+           d.algo, d.skip_tiles, d.d_terms, PRECISION, PRECISION_GENERIC, a_real, b_real, _tiles_key(d))
     hit = _wgrad_plans.get(key)
     if hit is None:
         d.KW = d.KH
@@ -757,7 +794,7 @@ class WgradBatch:
 
     def add(self, d, keep, finish, blocks, ntiles, slab_floats, kname, flops):
         key = (d.d.N, d.d.H, d.d.W, d.d.C, d.d.sn, d.d.sh, d.d.sw, d.d.n_in, d.d.sg, d.g.C, d.g.sn, d.g.sh, d.g.sw,
-               d.g.n_in, d.g.sg, d.precision, d.with_bias, d.skip_tiles, d.d_terms)
+               d.g.n_in, d.g.sg, d.precision, d.with_bias, d.skip_tiles, d.d_terms, _tiles_key(d))
         self.items.append((key, d, keep, finish, blocks, ntiles, slab_floats, kname, flops))
 
     def flush(self):
@@ -830,6 +867,20 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
         d.skip_tiles = sum(1 << i for i in range(min(32, ((ap + 63) // 64) * nbt)) if i not in need)
     # which kernel, how many blocks per pixel range, how many pixel tiles: the library's answer (csrc/dispatch.cpp)
     prec, plan, kname = _wgrad_plan(d, a, b)
+    if sub_blocks is not None and WGRAD_TILE_LIST and plan.tile_list_ok and ap % 32 == 0 and bp % 32 == 0:
+        # the useful 32 x 32 products, covered by tiles of freely chosen 32-channel groups (fewer than the 64-aligned ones?)
+        need = {(ga, gb) for sb in sub_blocks for ga in range(sb[0] // 32, (sb[0] + sb[1] + 31) // 32)
+                for gb in range((sb[2] + 31) // 32)}
+        cover = tile_cover(need, ap // 32, bp // 32)
+        if len(cover) <= L.WGRAD_TILES_MAX and len(cover) < plan.blocks - bin(int(d.skip_tiles)).count('1'):
+            d.skip_tiles, d.n_tiles, bias_done = 0, len(cover), set()
+            for i, (a0_, a1_, b0_, b1_, quads) in enumerate(cover):
+                t_ = d.tiles[i]
+                t_.a[0], t_.a[1], t_.b[0], t_.b[1], t_.quads = a0_, a1_, b0_, b1_, quads
+                t_.bias = 0 if {a0_, a1_} <= bias_done else 1        # every D group's bias sums are written by (at least) one tile
+                bias_done |= {a0_, a1_}
+            assert bias_done >= {ga for ga, _ in need}
+            prec, plan, kname = _wgrad_plan(d, a, b)
     halo, pc = bool(plan.halo), bool(plan.pc)
     blocks, ntiles = plan.blocks, plan.ntiles
     if halo:

@@ -230,3 +230,47 @@ def test_wgrad_plan_query_is_the_dispatch():
     assert p.tiny_ok == 1
     with pytest.raises(L.MT355Error):
         plan(1, 8, 8, 64, 64, 3, d_terms=7)
+    # tile lists (mt_wgrad.tiles): the 3 x 3 producer / consumer kernel takes them, blocks = listed tiles
+    assert plan(32, 64, 64, 128, 160, 3).tile_list_ok == 1 and plan(32, 64, 64, 128, 160, 3).blocks == 6
+    assert plan(32, 64, 64, 128, 160, 5).tile_list_ok == 0 and plan(32, 128, 128, 128, 128, 3, stride=2).tile_list_ok == 0
+
+    def listed(tiles, k=3, a_p=128, b_p=160, skip=0):
+        d = L.Wgrad()
+        d.d, d.g = _view(L, 32, 64, 64, a_p), _view(L, 32, 64, 64, b_p)
+        d.KH = d.KW = k
+        d.stride, d.pad, d.precision, d.d_terms, d.skip_tiles = 1, k // 2, L.PREC_F16X3, 1, skip
+        d.n_tiles = len(tiles)
+        for i, (a0, a1, b0, b1, q) in enumerate(tiles[:L.WGRAD_TILES_MAX]):
+            t = d.tiles[i]
+            t.a[0], t.a[1], t.b[0], t.b[1], t.quads, t.bias = a0, a1, b0, b1, q, 0
+        out = L.WgradPlan()
+        L.call('mt_wgrad_plan_query', ctypes.byref(d), a_p, b_p, ctypes.byref(out))
+        return out
+    cover = [(0, 1, 0, 1, 15), (2, 3, 0, 1, 15), (2, 3, 2, 3, 15), (1, 3, 2, 4, 9)]
+    assert listed(cover).blocks == 4
+    for bad in (dict(tiles=cover, k=5),                          # the 5 x 5 launches take no list
+                dict(tiles=cover, skip=1),                       # a list and a skip mask exclude one another
+                dict(tiles=[(0, 4, 0, 1, 15)]),                  # D group 4 of a 128-channel D
+                dict(tiles=[(0, 1, 0, 5, 15)]),                  # G group 5 of a 160-channel G
+                dict(tiles=[(0, 1, 0, 1, 0)]),                   # a tile that wants nothing
+                dict(tiles=cover * 3)):                          # more than MT_WGRAD_TILES_MAX
+        with pytest.raises(L.MT355Error):
+            listed(**bad)
+
+
+def test_tile_cover_of_block_triangular_products():
+    """engine.tile_cover: every wanted 32 x 32 product delivered exactly once, by as few tiles as a 2 x 2 grouping allows."""
+    from master_thesis_amd import engine as E
+    cases = {'dense block (model_chn.py:588-623)': ({(i, j) for i in range(4) for j in range(2 + i)}, 4, 5, 4),
+             'full 2 x 6': ({(i, j) for i in range(2) for j in range(6)}, 2, 6, 3),
+             'one product': ({(0, 0)}, 1, 1, 1),
+             'full 3 x 3': ({(i, j) for i in range(3) for j in range(3)}, 3, 3, 3),
+             'diagonal': ({(i, i) for i in range(4)}, 4, 4, 2)}
+    for name, (need, na, nb, ntiles) in cases.items():
+        tiles = E.tile_cover(need, na, nb)
+        assert len(tiles) == ntiles, (name, tiles)
+        got = []
+        for a0, a1, b0, b1, quads in tiles:
+            assert 1 <= quads <= 15 and a0 < na and a1 < na and b0 < nb and b1 < nb
+            got += [(ga, gb) for i, ga in enumerate((a0, a1)) for j, gb in enumerate((b0, b1)) if quads >> (2 * i + j) & 1]
+        assert sorted(got) == sorted(need), (name, tiles)

@@ -250,6 +250,50 @@ def test_weight_gradient_terms(mt, case):
         E.WGRAD_D_TERMS = old
 
 
+@pytest.mark.parametrize('geom', [(3, 32, 48), (2, 16, 16), (1, 21, 37)])
+def test_weight_gradient_tile_list(mt, geom):
+    """The four growth convolutions of a dense block (model_chn.py:588-623: 32 outputs each from 64 / 96 / 128 / 160
+    channels of one buffer, their output gradients side by side) as ONE weight-gradient launch: with the tile list
+    (mt_wgrad.tiles: four tiles of freely chosen 32-channel groups, engine.tile_cover) and with the 64-aligned tiles + skip
+    mask it replaced, both against fp64 convolutions -- weights and biases of every layer, both arithmetic widths."""
+    from master_thesis_amd import engine as E
+    n, h, w = geom
+    nf, gc = 64, 32
+    tag = 'wgtl.' + '.'.join(map(str, geom))
+    buf = S.uniform(tag + '.x', (n, h, w, nf + 4 * gc), -1, 1)
+    dz = S.uniform(tag + '.dz', (n, h, w, 4 * gc), -1, 1)
+    refs = []
+    for i in (1, 2, 3, 4):
+        cin = nf + (i - 1) * gc
+        wr = torch.zeros((gc, cin, 3, 3), dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(buf[..., :cin].permute(0, 3, 1, 2).double(), wr, None, padding=1)
+        dzi = dz[..., (4 - i) * gc: (5 - i) * gc]
+        g, = torch.autograd.grad(y, wr, dzi.permute(0, 3, 1, 2).double())
+        refs.append((g, dzi.double().sum((0, 1, 2))))
+    bufd, dzd = buf.to(dev()), dz.to(dev())
+    ws = [torch.zeros((gc, nf + (i - 1) * gc, 3, 3), device=dev()) for i in (1, 2, 3, 4)]
+    subs = [((4 - i) * gc, gc, nf + (i - 1) * gc, ws[i - 1]) for i in (1, 2, 3, 4)]
+    spec = E.LayerSpec('c', nf + 3 * gc, 4 * gc, 3, 1, 1)
+    old_t, old_l = E.WGRAD_D_TERMS, E.WGRAD_TILE_LIST
+    seen = set()
+    try:
+        with E.precision('f16x3'):
+            for terms, bound in ((2, 3e-6), (1, 5e-4)):
+                for use_list in (True, False):
+                    E.WGRAD_D_TERMS, E.WGRAD_TILE_LIST = terms, use_list
+                    E._wgrad_plans.clear()
+                    res = E.conv_backward_weight(spec, dzd, E.view_of(bufd[..., :nf + 3 * gc]), ws[0], sub_blocks=subs)
+                    seen.add(max(k[-1][0] if k[-1] else 0 for k in E._wgrad_plans))
+                    for (dw, db), (rw, rb) in zip(res, refs):
+                        e = float((dw.double().cpu() - rw).norm() / rw.norm())
+                        eb = float((db.double().cpu() - rb).norm() / rb.norm())
+                        assert e < bound and eb < bound, (terms, use_list, e, eb)
+    finally:
+        E.WGRAD_D_TERMS, E.WGRAD_TILE_LIST = old_t, old_l
+        E._wgrad_plans.clear()
+    assert seen == {0, 4}, f'tile lists seen: {seen} (the list path must have run with four tiles, the mask path without)'
+
+
 @pytest.mark.parametrize('case', [(2, 32, 32, 128, 128), (1, 24, 40, 64, 128), (1, 16, 16, 256, 256)])
 def test_conv5x5_f16x3_is_fp32_grade(mt, case):
     """The 5 x 5 stride-1 layers with 128-wide tiles run the 1-D Winograd F(2,5) transform (points 0, +-1, +-2, inf)
