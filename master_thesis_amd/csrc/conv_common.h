@@ -492,7 +492,42 @@ struct WgK {
   // (mt_wgrad.tiles, one 64-bit word each: a[0] | a[1] << 8 | b[0] << 16 | b[1] << 24 | quads << 32 | bias << 40)
   int ntl;
   unsigned long long tl[MT_WGRAD_TILES_MAX];
+  // block order of the halo-tile weight-gradient grids (wg_block): gx = channel tiles (x kernel-row groups) per pixel
+  // range, gy = pixel ranges (splits) per problem, nrg = pixel ranges of the launch (gy x problems of a batch); the launch
+  // is 1-D with gx * gyp blocks, gyp = nrg rounded up to 8
+  int gx, gy, gyp, nrg, xcd;      // xcd = 1: the XCD-aware order (launches with at least 8 pixel ranges)
 };
+#ifndef MT_WG_XCD
+#define MT_WG_XCD 1      // (0: the plain order -- channel tile fastest, then pixel range: A/B)
+#endif
+inline unsigned wg_grid(WgK* k, int gx, int splits, int problems = 1) {
+  const int ranges = splits * problems;                // pixel ranges of the launch (every problem of a batch has `splits`)
+  k->xcd = MT_WG_XCD && ranges >= 8;
+  k->gx = gx; k->gy = splits; k->nrg = ranges; k->gyp = k->xcd ? (ranges + 7) & ~7 : ranges;
+  return (unsigned)(gx * k->gyp);
+}
+#ifdef __HIPCC__
+// Blocks are dealt round-robin over the 8 XCDs in launch order, each XCD with its own L2.  The channel tiles of ONE
+// pixel range read the same pixels of D and G (a 2 x 2 tiling reads every byte twice, the dense block's four listed
+// tiles 2 - 2.4 times): they become consecutive blocks of ONE XCD -- in flight together, so that all but the first
+// find the pixels in that L2 -- instead of neighbours in launch order, which land on different XCDs.
+// Returns false for a padding block (pixel range beyond the last).  bx: channel tile, by: pixel range, bz: problem.
+__device__ __forceinline__ bool wg_block(const WgK& p, int& bx, int& by, int& bz) {
+  const int id = blockIdx.x;
+  int rg;                                              // pixel range of the launch: problem * splits + split
+  if (p.xcd) {
+    const int slot = id >> 3;
+    bx = slot % p.gx;
+    rg = (slot / p.gx) * 8 + (id & 7);
+  } else {
+    bx = id % p.gx;
+    rg = id / p.gx;
+  }
+  bz = rg / p.gy;
+  by = rg - bz * p.gy;
+  return rg < p.nrg;
+}
+#endif
 inline void wgk_tiles(const mt_wgrad* d, WgK* k) {
   k->ntl = d->n_tiles;
   for (int i = 0; i < MT_WGRAD_TILES_MAX; ++i) {

@@ -54,13 +54,13 @@ __global__ __launch_bounds__(256, OCC) void wgrad_halo_kernel(WgK p, int tiles_y
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  int bid = blockIdx.x;
+  int bid, split, bz_;
+  if (!wg_block(p, bid, split, bz_)) return;     // (XCD-aware block order: conv_common.h)
   const int bt = bid % p.btiles; bid /= p.btiles;
   const int at = bid % p.atiles; bid /= p.atiles;
   const int kh0 = kh_base + bid * KHB;     // first kernel row of this block
   if (at * p.btiles + bt < 32 && ((p.skip >> (at * p.btiles + bt)) & 1u)) return;   // tile nobody reads
   const int a0 = at * CH, b0 = bt * CH;
-  const int split = blockIdx.y;
   const int t_beg = split * tiles_per_split, t_end = min(ntiles, t_beg + tiles_per_split);
   const int HL = p.Hg << p.ups, WL = p.Wg << p.ups;
   const float scD = FMT ? pow2_scale(*p.damax) : 1.f, scG = FMT ? pow2_scale(*p.gamax) : 1.f;
@@ -271,7 +271,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
   // The block's 64 x 64 channel tile = four 32-channel groups: D channels aA.., aB.. (tile columns 0-31 / 32-63 of the
   // staged D image), G channels bA.., bB...  Regular grid: 64-aligned tiles (aB = aA + 32).  Tile list (mt_wgrad.tiles,
   // 3 x 3 only): the groups are free, `quads` says which of the four 32 x 32 products (one per MFMA wave) are wanted.
-  int bid = blockIdx.x;
+  int bid, split, bz_;
+  if (!wg_block(p, bid, split, bz_)) return;     // (XCD-aware block order: the tiles of one pixel range share an L2)
   int aA, aB, bA, bB, kh0;
   unsigned quads = 15u;
   bool bias_tile;
@@ -290,11 +291,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_pc_kernel(WgK p, int tiles_y, in
     aA = at * CH; aB = aA + 32; bA = bt * CH; bB = bA + 32;
     bias_tile = bt == 0;
   }
-  const int split = blockIdx.y;
   const float *pd, *pg, *pdamax, *pgamax;
   float* pslabs;
   if constexpr (BATCH) {
-    const int z = blockIdx.z;
+    const int z = bz_;
     pd = tab.d[z]; pg = tab.g[z]; pslabs = tab.slabs[z]; pdamax = tab.damax[z]; pgamax = tab.gamax[z];
   } else {
     pd = p.d; pg = p.g; pslabs = p.slabs; pdamax = p.damax; pgamax = p.gamax;
@@ -533,8 +533,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_thin_kernel(WgK p, int tiles_y, 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool producer = wave >= 4;
-  const int at = blockIdx.x, a0 = at * CH;
-  const int split = blockIdx.y;
+  int at, split, bz_;
+  if (!wg_block(p, at, split, bz_)) return;
+  const int a0 = at * CH;
   const int t_beg = split * tiles_per_split, t_end = min(ntiles, t_beg + tiles_per_split);
   const float scD = FMT ? pow2_scale(*p.damax) : 1.f, scG = FMT ? pow2_scale(*p.gamax) : 1.f;
   const float inv = 1.f / (scD * scG), inv_d = 1.f / scD;
@@ -716,6 +717,7 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   wgk_tiles(d, &k);
   const bool pc = sel.pc, tall = sel.tall, thin = sel.thin;
   const unsigned ctiles = k.ntl > 0 ? k.ntl : k.atiles * k.btiles;      // channel tiles of a producer / consumer launch
+  dim3 gpc;                                                              // its grid (wg_grid also fills k's block-order fields: before any launch reads k)
   const int trows = sel.trows, dterms = sel.d_terms;
   const int tiles_y = (k.Hd + trows - 1) / trows, tiles_x = (k.Wd + 15) / 16;
   const int ntiles = d->d.N * tiles_y * tiles_x;
@@ -727,10 +729,10 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   do { if (dterms == 1) hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2, 4, 1>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE); \
        else hipLaunchKernelGGL((wgrad_halo_kernel<KS, KHB, 2, FMT, 1, 2>), GRID, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE); } while (0)
 #define MT_WGPC(KS, KHB, FMT, KH_BASE) \
-  do { if (dterms == 1) hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT, false, 1>), dim3(ctiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); \
-       else hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), dim3(ctiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); } while (0)
+  do { if (dterms == 1) hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT, false, 1>), gpc, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); \
+       else hipLaunchKernelGGL((wgrad_pc_kernel<KS, KHB, FMT>), gpc, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, KH_BASE, WgOne{}); } while (0)
   if (thin) {
-    const dim3 grid(k.atiles, d->splits);
+    const dim3 grid(wg_grid(&k, k.atiles, d->splits));
     if (d->KH == 3) {
       if (prec == MT_PREC_F16X3) hipLaunchKernelGGL((wgrad_thin_kernel<3, 1>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
       else hipLaunchKernelGGL((wgrad_thin_kernel<3, 0>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias);
@@ -741,9 +743,10 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
     return 1;
   }
   if (pc) {
+    gpc = dim3(wg_grid(&k, ctiles, d->splits));
     const bool f16 = prec == MT_PREC_F16X3;
     if (d->KH == 3 && f16 && trows == 8)
-      hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, false, 1, 8>), dim3(ctiles, d->splits), dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, WgOne{});
+      hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, false, 1, 8>), gpc, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, WgOne{});
     else if (d->KH == 3) { if (f16) MT_WGPC(3, 3, 1, 0); else MT_WGPC(3, 3, 0, 0); }
     // 5 x 5: kernel rows {0,1} | {2,3} | {4} (15 accumulator tiles would not leave the MFMA waves
     // their operand registers at two waves per SIMD; the staging is off the critical path here)
@@ -753,13 +756,13 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
   }
 #undef MT_WGPC
   if (d->stride == 2) {      // stride-2 gather: all 9 taps, or kernel rows {0,1,2} | {3,4}
-    dim3 grid(k.atiles * k.btiles, d->splits);
+    dim3 grid(wg_grid(&k, k.atiles * k.btiles, d->splits));
     const bool f16 = prec == MT_PREC_F16X3;
     if (d->KH == 3) { if (f16) MT_WGH2(3, 3, 1, grid, 0); else MT_WGH2(3, 3, 0, grid, 0); }
     else if (f16) { MT_WGH2(5, 3, 1, grid, 0); MT_WGH2(5, 2, 1, grid, 3); }
     else { MT_WGH2(5, 3, 0, grid, 0); MT_WGH2(5, 2, 0, grid, 3); }
   } else if (d->KH == 3) {   // all nine taps per block, one block per CU (the 9 accumulator tiles need the registers)
-    dim3 grid(k.atiles * k.btiles, d->splits);
+    dim3 grid(wg_grid(&k, k.atiles * k.btiles, d->splits));
     if (prec == MT_PREC_BF16X6) MT_WGH(3, 3, 3, 0, 1, grid, 0);
     else if (tall && prec == MT_PREC_BF16X3)
       hipLaunchKernelGGL((wgrad_halo_kernel<3, 3, 2, 0, 1, 1, 8>), grid, dim3(256), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0);
@@ -768,13 +771,13 @@ int mt_wgrad_halo_try_launch(const mt_wgrad* d, void* stream) {
     else if (prec == MT_PREC_BF16X3) MT_WGH(3, 3, 2, 0, 1, grid, 0);
     else MT_WGH(3, 3, 2, 1, 1, grid, 0);
   } else if (sel.rows5) {   // one kernel row (5 taps) per block
-    dim3 grid(k.atiles * k.btiles * 5, d->splits);
+    dim3 grid(wg_grid(&k, k.atiles * k.btiles * 5, d->splits));
     if (prec == MT_PREC_BF16X6) MT_WGH(5, 1, 3, 0, 2, grid, 0);
     else if (prec == MT_PREC_BF16X3) MT_WGH(5, 1, 2, 0, 2, grid, 0);
     else MT_WGH(5, 1, 2, 1, 2, grid, 0);
   } else {            // kernel rows {0,1,2} and {3,4}: 15 / 10 taps per block, one block per CU; each
                       // pixel tile is staged twice instead of five times
-    dim3 grid(k.atiles * k.btiles, d->splits);
+    dim3 grid(wg_grid(&k, k.atiles * k.btiles, d->splits));
     if (prec == MT_PREC_BF16X3) { MT_WGH(5, 3, 2, 0, 1, grid, 0); MT_WGH(5, 2, 2, 0, 1, grid, 3); }
     else { MT_WGH(5, 3, 2, 1, 1, grid, 0); MT_WGH(5, 2, 2, 1, 1, grid, 3); }
   }
@@ -833,7 +836,7 @@ extern "C" int mt_wgrad_run_batch(const mt_wgrad* descs, int32_t n, void* stream
   const int tiles_y = (k.Hd + trb - 1) / trb, tiles_x = (k.Wd + 15) / 16;
   const int ntiles = d->d.N * tiles_y * tiles_x;
   const int tps = (ntiles + d->splits - 1) / d->splits;
-  const dim3 grid(k.ntl > 0 ? k.ntl : k.atiles * k.btiles, d->splits, n);
+  const dim3 grid(wg_grid(&k, k.ntl > 0 ? k.ntl : k.atiles * k.btiles, d->splits, n));
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (prec == MT_PREC_F16X3 && dterms == 1 && trb == 8)
     hipLaunchKernelGGL((wgrad_pc_kernel<3, 3, 1, true, 1, 8>), grid, dim3(512), 0, s, k, tiles_y, tiles_x, tps, ntiles, d->with_bias, 0, tab);
