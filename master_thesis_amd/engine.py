@@ -101,7 +101,7 @@ WGRAD_TILE_LIST = os.environ.get('MT355_WGRAD_TILE_LIST', '1') != '0'
 # decision (csrc/dispatch.cpp) is queried through the ABI -- mt_conv_plan_query / mt_wgrad_plan_query -- before a weight
 # is packed or a workspace is sized, and the profiling labels are the names it reports.  Plans are cached by geometry
 # (a ctypes call per launch would cost the eager path ~2 us x 2300 launches per CHN step).
-_conv_plans, _wgrad_plans = {}, {}
+_conv_plans, _wgrad_plans, _tile_covers = {}, {}, {}
 KERNEL_INFO = {}          # profiling label -> (MFMA products per multiply-add, executed / algorithmic MFMA work)
 
 
@@ -869,9 +869,12 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     prec, plan, kname = _wgrad_plan(d, a, b)
     if sub_blocks is not None and WGRAD_TILE_LIST and plan.tile_list_ok and ap % 32 == 0 and bp % 32 == 0:
         # the useful 32 x 32 products, covered by tiles of freely chosen 32-channel groups (fewer than the 64-aligned ones?)
-        need = {(ga, gb) for sb in sub_blocks for ga in range(sb[0] // 32, (sb[0] + sb[1] + 31) // 32)
-                for gb in range((sb[2] + 31) // 32)}
-        cover = tile_cover(need, ap // 32, bp // 32)
+        ckey = (tuple((sb[0], sb[1], sb[2]) for sb in sub_blocks), ap, bp)
+        cover = _tile_covers.get(ckey)
+        if cover is None:
+            need = {(ga, gb) for sb in sub_blocks for ga in range(sb[0] // 32, (sb[0] + sb[1] + 31) // 32)
+                    for gb in range((sb[2] + 31) // 32)}
+            cover = _tile_covers[ckey] = tile_cover(need, ap // 32, bp // 32)
         if len(cover) <= L.WGRAD_TILES_MAX and len(cover) < plan.blocks - bin(int(d.skip_tiles)).count('1'):
             d.skip_tiles, d.n_tiles, bias_done = 0, len(cover), set()
             for i, (a0_, a1_, b0_, b1_, quads) in enumerate(cover):
@@ -879,7 +882,6 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
                 t_.a[0], t_.a[1], t_.b[0], t_.b[1], t_.quads = a0_, a1_, b0_, b1_, quads
                 t_.bias = 0 if {a0_, a1_} <= bias_done else 1        # every D group's bias sums are written by (at least) one tile
                 bias_done |= {a0_, a1_}
-            assert bias_done >= {ga for ga, _ in need}
             prec, plan, kname = _wgrad_plan(d, a, b)
     halo, pc = bool(plan.halo), bool(plan.pc)
     blocks, ntiles = plan.blocks, plan.ntiles
