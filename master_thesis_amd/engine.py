@@ -81,7 +81,9 @@ class precision:
         PRECISION = self.old
 
 
-WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '512'))     # blocks in flight a producer / consumer weight gradient aims at
+# blocks a producer / consumer weight-gradient launch aims at: ONE round of the 256 CUs (one 512-thread block per CU).  Round 4, same box,
+# DFPN step's weight gradients: 256 blocks 31.4 ms, 512 (two rounds: twice the slabs, twice the pipeline fills) 32.3, 384 38.9, 128 52.8
+WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '256'))
 # 16-bit terms of dY that enter a weight gradient on the producer / consumer kernel (mt_wgrad.d_terms): 2 = both
 # (three partial products, fp32-grade per product); 1 = the leading term only (two products, default since round 3).
 # With one term dY is rounded to 11 bits PER PIXEL before it is summed over 10^5 .. 10^6 pixels: independent rounding
