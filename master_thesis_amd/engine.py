@@ -84,6 +84,7 @@ class precision:
 # blocks a producer / consumer weight-gradient launch aims at: ONE round of the 256 CUs (one 512-thread block per CU).  Round 4, same box,
 # DFPN step's weight gradients: 256 blocks 31.4 ms, 512 (two rounds: twice the slabs, twice the pipeline fills) 32.3, 384 38.9, 128 52.8
 WGRAD_PC_BLOCKS = int(os.environ.get('MT355_WGRAD_PC_BLOCKS', '256'))
+WGRAD_HALO_BLOCKS = int(os.environ.get('MT355_WGRAD_HALO_BLOCKS', '512'))    # the single-role kernels (stride-2 gathers, three-term splits)
 # 16-bit terms of dY that enter a weight gradient on the producer / consumer kernel (mt_wgrad.d_terms): 2 = both
 # (three partial products, fp32-grade per product); 1 = the leading term only (two products, default since round 3).
 # With one term dY is rounded to 11 bits PER PIXEL before it is summed over 10^5 .. 10^6 pixels: independent rounding
@@ -888,7 +889,7 @@ def conv_backward_weight(spec, dz, xin_view, w, need_bias=True, scale=1.0, dz_am
     halo, pc = bool(plan.halo), bool(plan.pc)
     blocks, ntiles = plan.blocks, plan.ntiles
     if halo:
-        want = WGRAD_PC_BLOCKS if pc else 512        # blocks in flight: one 512-thread block per CU for pc
+        want = WGRAD_PC_BLOCKS if pc else WGRAD_HALO_BLOCKS        # blocks of the launch: one 512-thread block per CU for pc
         d.splits = max(1, min((want + blocks - 1) // blocks, ntiles // 8 if ntiles >= 8 else 1, 256))
     else:
         d.skip_tiles = 0
