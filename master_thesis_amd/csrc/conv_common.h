@@ -415,6 +415,22 @@ template <int NS, int FMT, int SHADOW = MT_SHADOW_DEFAULT>
 __device__ __forceinline__ void split4f(const f32x4& v, float scale, bf16x4 (&out)[NS]) {
   if constexpr (FMT == 0) {
     split4<NS>(v, out);
+  } else if constexpr (SHADOW == 3) {
+    // (lab) FOUR instructions per value pair: the scale rides in the mixed-precision FMAs -- hi = fp16(v * scale + 0),
+    // lo = fp16(v * scale - hi) (v * scale is exact: a power of two) -- instead of two v_mul_f32 and a v_cvt_pk_f16_f32
+    // in front of them.  Bit-identical to the other forms; all four instructions share the matrix pipe.
+    static_assert(NS == 2, "f16x3 uses two fp16 terms");
+    unsigned hi[2], lo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi[j]) : "v"(v[2 * j]), "v"(scale));
+      asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi[j]) : "v"(v[2 * j + 1]), "v"(scale));
+      asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo[j]) : "v"(v[2 * j]), "v"(scale), "v"(hi[j]));
+      asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo[j]) : "v"(v[2 * j + 1]), "v"(scale), "v"(hi[j]));
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    out[0] = __builtin_bit_cast(bf16x4, u32x2{hi[0], hi[1]});
+    out[1] = __builtin_bit_cast(bf16x4, u32x2{lo[0], lo[1]});
   } else if constexpr (SHADOW == 2) {
     // The fewest instructions (5 per value pair; hipcc's own form mixes both of the others and spends ~10): for code
     // whose bound is VALU issue, not the matrix pipe (the xi-split kernels: 32 output channels per transformed value).
