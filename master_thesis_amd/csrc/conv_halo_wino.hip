@@ -231,9 +231,15 @@ __device__ unsigned long long winox_trace[4096 * 16];
 #ifndef MT_WINOX_ABL          // (lab ablations: 1 no halo loads, 2 no transform / split / image stores, 3 no MFMAs, 4 no weight loads, 5 no epilogue)
 #define MT_WINOX_ABL 0
 #endif
-template <int FMT, int TN>
-__global__ __launch_bounds__(256, TN == 1 ? MT_WINOX_OCC : 2) void igemm_winox_kernel(ConvK p, int tiles_y, int tiles_x) {
-  constexpr int NS = 2, CK = 32, TH = 8, TW = 16, BN = 32 * TN, TM = 2;
+#ifndef MT_WINOX_TH4          // 1: launches of the 32-wide variant that would not fill two blocks per CU twice run 4 x 16-pixel tiles
+#define MT_WINOX_TH4 0        // (twice the blocks, half the chain per block; four blocks per CU)
+#endif
+#ifndef MT_WINOX_TH4_BELOW    // ... below this many 8-row tiles
+#define MT_WINOX_TH4_BELOW 1025
+#endif
+template <int FMT, int TN, int TH_ = 8>
+__global__ __launch_bounds__(256, TH_ == 4 ? 4 : (TN == 1 ? MT_WINOX_OCC : 2)) void igemm_winox_kernel(ConvK p, int tiles_y, int tiles_x) {
+  constexpr int NS = 2, CK = 32, TH = TH_, TW = 16, BN = 32 * TN, TM = TH / 4;
   constexpr int NTX = TW / 2, ROWS = TH + 2;
   constexpr int ENT = CK, ROW_E = 4 * NTX * ENT + 8, PLANE_E = ROWS * ROW_E;
   constexpr int NIT = ROWS * NTX * (CK / 4), RI = (NIT + 255) / 256;
@@ -808,7 +814,10 @@ void mt_halo_wino_launch(const void* kp, int fmt, int kernel, void* stream) {
       if (fmt) hipLaunchKernelGGL((igemm_winox_kernel<1, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
       else hipLaunchKernelGGL((igemm_winox_kernel<0, 2>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
     } else {
-      if (fmt) hipLaunchKernelGGL((igemm_winox_kernel<1, 1>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
+      if (MT_WINOX_TH4 && fmt && nt < MT_WINOX_TH4_BELOW) {
+        const int ty4 = (k.Ho + 3) / 4;
+        hipLaunchKernelGGL((igemm_winox_kernel<1, 1, 4>), dim3((unsigned)k.N * ty4 * tiles_x, 1), dim3(256), 0, s, k, ty4, tiles_x);
+      } else if (fmt) hipLaunchKernelGGL((igemm_winox_kernel<1, 1>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
       else hipLaunchKernelGGL((igemm_winox_kernel<0, 1>), dim3(nt, 1), dim3(256), 0, s, k, tiles_y, tiles_x);
     }
     return;
