@@ -511,6 +511,50 @@ def test_batched_weight_gradients_match_single_launches(mt):
     assert_close(deferred[1][0], wr.grad, what='batched weight gradient vs torch')
 
 
+def test_weight_gradient_block_order_with_ragged_range_counts(mt, monkeypatch):
+    """The weight-gradient grids are 1-D and a block decodes (channel tile, pixel range, problem) so that the tiles of
+    one range sit on one XCD (conv_common.h: wg_block); grids are padded to eight ranges and launches with fewer than
+    eight keep the plain order.  Every count of pixel ranges must give the same gradient: 1, 7 (plain order), 8, 13, 24,
+    61 ranges (padding blocks), single launches and a batch of three problems x 5 ranges (15: ragged across problems)."""
+    from master_thesis_amd import engine as E
+    spec = E.LayerSpec('c', 128, 128, 3, 1, 0)
+    x = S.uniform('wgord.x', (8, 64, 64, 128), -1, 1).to(dev())
+    dz = S.uniform('wgord.dz', (8, 64, 64, 128), -1, 1).to(dev())
+    w = torch.zeros((128, 128, 3, 3), device=dev())
+    wr = torch.zeros((128, 128, 3, 3), dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wr, None, padding=1).backward(dz.permute(0, 3, 1, 2).double().cpu())
+    ref, ref_b = wr.grad, dz.double().sum((0, 1, 2)).cpu()
+    seen = []
+    real_call = E.L.call
+
+    def spy(name, *a):
+        if name == 'mt_wgrad_run':
+            seen.append(a[0]._obj.splits)
+        return real_call(name, *a)
+    monkeypatch.setattr(E.L, 'call', spy)
+    monkeypatch.setattr(E, 'WGRAD_D_TERMS', 2)
+    with E.precision('f16x3'):
+        for ranges in (1, 7, 8, 13, 24, 61):
+            monkeypatch.setattr(E, 'WGRAD_PC_BLOCKS', 4 * ranges)          # 4 channel tiles of 64 x 64 per range
+            dw, db = E.conv_backward_weight(spec, dz, E.view_of(x), w)
+            assert seen[-1] == ranges, (seen, ranges)
+            e = float((dw.double().cpu() - ref).norm() / ref.norm())
+            eb = float((db.double().cpu() - ref_b).norm() / ref_b.norm())
+            assert e < 3e-6 and eb < 3e-6, (ranges, e, eb)
+        # a batch: three problems x five ranges = 15 ranges of the launch
+        monkeypatch.setenv('MT355_WGRAD_BATCH_SPLITS', '5')
+        probs = [(x, dz), (x.flip(0).contiguous(), dz.flip(0).contiguous()), (x * 0.5, dz * 2.0)]
+        batch = E.WgradBatch()
+        out = [E.conv_backward_weight(spec, d_, E.view_of(x_), w, defer=batch) for x_, d_ in probs]
+        assert len(batch.items) == 3
+        batch.flush()
+    for dw, db in out:            # (flipping the images / scaling by 0.5 x 2 leaves the gradient unchanged)
+        e = float((dw.double().cpu() - ref).norm() / ref.norm())
+        eb = float((db.double().cpu() - ref_b * (1.0 if db is not out[2][1] else 2.0)).norm() / ref_b.norm())
+        assert e < 3e-6, e
+        assert eb < 3e-6, eb
+
+
 def test_conv_stack_chain(mt, precision):
     """A 3-layer chain with fused ReLU gating in the backward."""
     from master_thesis_amd import engine as E
